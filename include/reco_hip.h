@@ -1,0 +1,177 @@
+/*
+ * reco_hip.h -- C ABI of the MI355X (gfx950) scoring engine.
+ *
+ * This is the drop-in boundary for the reference's forward/scoring hot path
+ * (SURVEY.md section 8b).  The reference itself has no native code and no FFI:
+ * every entry point below replaces a chain of stock ATen calls made from the
+ * reference's Python, cited per function as <file>:<line> relative to the
+ * reference root.  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - floats are fp32, contiguous, row-major; Linear weights are [out, in] as nn.Linear stores them;
+ *   - ids (users, items, candidate lists) are int64 as the reference's torch LongTensors; returned
+ *     top-k positions are int32;
+ *   - `stream` is a hipStream_t passed as void*; work is only enqueued, never synchronised,
+ *     unless the comment says "synchronises";
+ *   - return 0 on success, a negative RECO_E* code otherwise; reco_last_error() gives the
+ *     thread-local message;
+ *   - nothing allocates except *_create (the packed-model handles) -- scratch memory is
+ *     brought in by the caller as `ws` / `ws_bytes` (query the size with *_workspace_bytes).
+ */
+#ifndef RECO_HIP_H
+#define RECO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RECO_OK          0
+#define RECO_EINVAL     -1   /* bad argument / unsupported shape  -> ValueError   */
+#define RECO_EHIP       -2   /* HIP runtime failure               -> RuntimeError */
+#define RECO_ENOMEM     -3   /* workspace too small / hipMalloc   -> MemoryError  */
+#define RECO_EINDEX     -4   /* id out of range (see reco_*_status) -> IndexError */
+
+/* epilogue applied to the logit / GEMM output */
+#define RECO_ACT_NONE     0
+#define RECO_ACT_RELU     1
+#define RECO_ACT_SIGMOID  2
+#define RECO_ACT_CLAMP    3   /* clamp(x, lo, hi)            src/api/core/inference_engine.py:232 */
+#define RECO_ACT_RATING   4   /* sigmoid(x)*(hi-lo)+lo       src/ncf/evaluate_ncf_rating.py:144-146 */
+
+int         reco_abi_version(void);
+const char* reco_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K-a  embedding gathers (HBM-bound)
+ * replaces nn.Embedding.__call__            src/helpers/ncf_model.py:207-208,220-221
+ * ---------------------------------------------------------------------------------------- */
+
+/* out[b, :] = table[idx[b], :]   dim % 4 == 0.  Out-of-range ids are clamped and counted in *oob
+ * (device int32, nullable). */
+int reco_gather_rows(const float* table, int64_t rows, int dim, const int64_t* idx, int64_t B,
+                     float* out, int32_t* oob, void* stream);
+
+/* Fused 4-table NeuMF gather: the tensors the reference materialises before its MLP,
+ *   gmf_prod[b, :]  = Eu_g[user[b]] * Ei_g[item[b]]                  ncf_model.py:207-211
+ *   mlp_in[b, :]    = [Eu_m[user[b]] | Ei_m[item[b]]]  (user half first) ncf_model.py:220-224
+ * dg % 4 == 0, dm % 4 == 0.  Either output may be NULL to skip that half. */
+int reco_neumf_gather(const float* Eu_g, const float* Ei_g, const float* Eu_m, const float* Ei_m,
+                      int64_t n_users, int64_t n_items, int dg, int dm,
+                      const int64_t* user, const int64_t* item, int64_t B,
+                      float* gmf_prod, float* mlp_in, int32_t* oob, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K-c  Linear layer as an fp32 MFMA GEMM with fused epilogue
+ *   C[m, n] = act( sum_k A[row(m), k] * W[n, k] + bias[n] )
+ * replaces nn.Linear + Sigmoid/ReLU/clamp   src/autorec/utils/model.py:25-33,
+ *                                           src/hybridautorecncf/evaluate_hybridautorecncf_rating.py:78-106
+ * a_rows (nullable, int64[M]) gathers A rows: row(m) = a_rows[m], else m.  lda/ldw/ldc are row
+ * strides in floats (so W may be a column block of a wider matrix).
+ * ---------------------------------------------------------------------------------------- */
+int reco_linear_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_t a_row_limit, int64_t M,
+                    const float* W, int64_t ldw, const float* bias, int64_t N, int64_t K,
+                    int act, float lo, float hi, float* C, int64_t ldc, void* stream);
+
+/* AutoRec forward: out = act( sigmoid(X We^T + be) Wd^T + bd )        src/autorec/utils/model.py:31-33
+ * X [B, n_in], We [hidden, n_in], Wd [n_in, hidden], hidden_ws [B, hidden] (caller scratch),
+ * out [B, n_in].  act = RECO_ACT_NONE (the module's forward) or RECO_ACT_CLAMP with lo/hi
+ * (the engines' clamp(1,5), inference_engine.py:232, helper.py:289). */
+int reco_autorec_forward(const float* X, int64_t B, const float* We, const float* be,
+                         const float* Wd, const float* bd, int64_t n_in, int64_t hidden,
+                         int act, float lo, float hi, float* hidden_ws, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K-b  fused scoring tower (NeuMF, MLP-only, GMF-only, Hybrid head)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct reco_tower reco_tower_t;
+
+typedef struct reco_tower_desc {
+    /* embedding tables (borrowed, must outlive the handle).  NULL when the branch is absent.
+     * NeuMF: src/helpers/ncf_model.py:61-70.  Hybrid head: the "tables" are the encoder
+     * latents zu [U,64] / zi [I,64] for BOTH gmf and mlp (evaluate_hybridautorecncf_rating.py:167-173). */
+    const float* user_gmf;   /* [n_users, dg] */
+    const float* item_gmf;   /* [n_items, dg] */
+    const float* user_mlp;   /* [n_users, dm] */
+    const float* item_mlp;   /* [n_items, dm] */
+    int64_t n_users, n_items;
+    int32_t dg;              /* GMF width: 32 (NeuMF factor_num) or 64 (Hybrid latent); 0 = no GMF branch */
+    int32_t dm;              /* MLP embedding width per side: 128 (NeuMF) or 64 (Hybrid); 0 = no MLP branch */
+    /* MLP tower, nn.Linear layout [out,in]:  ncf_model.py:84-99 (MLP_layers.{1,4,7}),
+     * hybrid: ncf.mlp.{0,3}.  n_layers = 3 (2dm->128->64->32) or 2 (2dm->128->64). ReLU after every layer. */
+    int32_t n_layers;
+    int32_t layer_out[3];    /* output width of each layer; the MFMA path requires {128, 64, 32} / {128, 64} */
+    const float* W[3];
+    const float* b[3];
+    /* predict layer: [gmf half | mlp half]  ncf_model.py:113,240-246; hybrid ncf.output */
+    const float* w_predict;  /* [dg + mlp_out] */
+    const float* b_predict;  /* [1] */
+    int32_t act;             /* RECO_ACT_NONE (logit, ncf_model.py:246-249) or RECO_ACT_RATING */
+    float lo, hi;
+} reco_tower_desc_t;
+
+/* Packs the weights into the MFMA/LDS image and precomputes the layer-1 projections
+ *   P[u] = W1[:, :dm] Eu_m[u] + b1,  Q[i] = W1[:, dm:] Ei_m[i]        (exact split of ncf_model.py:224-227 layer 1)
+ * Allocates device memory; synchronises `stream`. */
+int  reco_tower_create(const reco_tower_desc_t* desc, void* stream, reco_tower_t** out);
+void reco_tower_destroy(reco_tower_t* t);
+
+/* forward(user, item) -> score[B]           src/helpers/ncf_model.py:188-249
+ * Out-of-range ids never fault: they are clamped and counted; reco_tower_status() reports them. */
+int reco_tower_score_pairs(reco_tower_t* t, const int64_t* user, const int64_t* item, int64_t B,
+                           float* out, void* stream);
+
+/* Score B pairs whose embedding rows are handed over directly (row b of each matrix belongs to
+ * pair b) -- the Hybrid forward, where every pair brings its own encoder latents
+ * (evaluate_hybridautorecncf_rating.py:197-208).  u_gmf/i_gmf [B,dg], u_mlp/i_mlp [B,dm];
+ * for the Hybrid head pass the same latent matrix for gmf and mlp.  The handle may have been
+ * created without tables (n_users = n_items = 0). */
+size_t reco_tower_rows_workspace_bytes(int64_t B);
+int reco_tower_score_rows(reco_tower_t* t, const float* u_gmf, const float* i_gmf,
+                          const float* u_mlp, const float* i_mlp, int64_t B, float* out,
+                          void* ws, size_t ws_bytes, void* stream);
+
+/* Number of out-of-range ids seen since the last call (and resets it).  Synchronises `stream`. */
+int64_t reco_tower_status(reco_tower_t* t, void* stream);
+
+/* Full (user x candidate) score matrix: out[u, n] = score(users[u], cands[n])
+ * replaces the per-user loop around model(user_t, item_t)  src/api/core/inference_engine.py:149-164
+ * users NULL -> user_base + u;  cands NULL -> n.  out row stride ld_out (floats).
+ * Recomputes the layer-1 projections for exactly these users/candidates inside the call. */
+size_t reco_tower_matrix_workspace_bytes(int64_t U, int64_t N);
+int reco_tower_score_matrix(reco_tower_t* t, const int64_t* users, int64_t user_base, int64_t U,
+                            const int64_t* cands, int64_t N, float* out, int64_t ld_out,
+                            void* ws, size_t ws_bytes, void* stream);
+
+/* score_matrix + per-user top-k (K-d), user-chunked so the score rows live only in `ws`.
+ * replaces model(...) + np.argsort(scores)[::-1][:k]       inference_engine.py:162-166
+ * exclude (nullable, uint8 [U, N], row stride ld_ex) applies helper.py:313:
+ *   score = score*(1-seen) - seen*1e10.
+ * out_ids [U,k] int32 = POSITIONS in the candidate list (== item ids when cands is NULL),
+ * out_scores [U,k]; order: descending score, ascending position among equals.
+ * k <= 128. */
+size_t reco_tower_topk_workspace_bytes(int64_t U, int64_t N, int k);
+int reco_tower_score_topk(reco_tower_t* t, const int64_t* users, int64_t user_base, int64_t U,
+                          const int64_t* cands, int64_t N, int k,
+                          const uint8_t* exclude, int64_t ld_ex,
+                          int32_t* out_ids, float* out_scores,
+                          void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K-d  per-row top-k select (wavefront-level)
+ * replaces np.argsort(...)[::-1][:k] (inference_engine.py:166), torch.topk (ncf.ipynb cell 8),
+ *          np.argsort(p)[-k:][::-1] (helper.py:335), list.sort(reverse=True)[:k] (inference_engine.py:294,341)
+ * scores [rows, N] with row stride ld.  NaN ranks first (as numpy/torch).  k <= 128, k <= N.
+ * ---------------------------------------------------------------------------------------- */
+size_t reco_topk_workspace_bytes(int64_t rows, int64_t N, int k);
+int reco_topk_rows(const float* scores, int64_t rows, int64_t N, int64_t ld, int k,
+                   const uint8_t* exclude, int64_t ld_ex,
+                   int32_t* out_ids, float* out_vals, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECO_HIP_H */

@@ -1,0 +1,121 @@
+"""Item-based / user-based AutoRec whose forward runs on the MI355X fp32-MFMA GEMM kernel.
+
+Drop-in for `autorec.utils.model.AutoRec` (src/autorec/utils/model.py:5-33): same constructor, same
+state_dict keys (encoder.0.{weight,bias}, decoder.0.{weight,bias}), same
+forward(x: float32[B, n_in]) -> float32[B, n_in].  Sigmoid and clamp are GEMM epilogues.
+
+Extended entry points cover what the reference's engines build on top of forward with Python loops
+(SURVEY 3.2 / 3.4 / 8f-N1): whole-matrix reconstruction, masked per-user top-K, and a cached-hidden
+serving path that turns a /autorec/recommend request into one 500-wide GEMV row.
+"""
+import weakref
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+
+_dev_cache = weakref.WeakKeyDictionary()
+
+
+class AutoRec(nn.Module):
+    def __init__(self, num_users: int, num_items: int, num_hidden_units: int, item_based: bool = True) -> None:
+        super().__init__()
+        self.num_users = num_users
+        self.num_items = num_items
+        self.num_hidden_units = num_hidden_units
+        self.item_based = item_based
+        width = num_users if item_based else num_items        # an item vector holds one rating per user
+        self.encoder = nn.Sequential(nn.Linear(width, num_hidden_units), nn.Sigmoid())
+        self.decoder = nn.Sequential(nn.Linear(num_hidden_units, width))
+
+    # -- weights on the compute device ------------------------------------------------------------------------
+    def _weights(self, device):
+        ps = (self.encoder[0].weight, self.encoder[0].bias, self.decoder[0].weight, self.decoder[0].bias)
+        sig = (str(device),) + tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
+        hit = _dev_cache.get(self)
+        if hit is None or hit[0] != sig:
+            hit = (sig, tuple(p.detach().to(device=device, dtype=torch.float32).contiguous() for p in ps), {})
+            _dev_cache[self] = hit
+        return hit
+
+    @staticmethod
+    def _device_of(x):
+        ops.require_gpu()
+        return x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device())
+
+    # -- reference interface ----------------------------------------------------------------------------------
+    def forward(self, input_data: torch.Tensor) -> torch.Tensor:
+        return self.reconstruct(input_data, clamp=None)
+
+    # -- extended ---------------------------------------------------------------------------------------------
+    def reconstruct(self, input_data, clamp=(1.0, 5.0)):
+        """decoder(sigmoid(encoder(x))) with the engines' clamp fused (inference_engine.py:231-232)."""
+        device = self._device_of(input_data)
+        x = input_data.to(device=device, dtype=torch.float32)
+        squeeze = x.dim() == 1
+        if squeeze:
+            x = x.unsqueeze(0)
+        we, be, wd, bd = self._weights(device)[1]
+        out = ops.autorec_forward(x, we, be, wd, bd, clamp)
+        if squeeze:
+            out = out.squeeze(0)
+        return out if out.device == input_data.device else out.to(input_data.device)
+
+    def reconstruct_all(self, train_matrix, clamp=(1.0, 5.0)):
+        """R_hat[users, items] for a [users, items] rating matrix, in one batched forward.
+
+        Replaces the 3,706-iteration loop of helper.py:281-292 / inference_engine.py:268-272.
+        Item-based: the batch is the transposed matrix (row i = item i's ratings from all users) and the
+        result is transposed back, so R_hat[u, i] = forward(train[:, i])[u].
+        """
+        device = self._device_of(train_matrix)
+        m = train_matrix.to(device=device, dtype=torch.float32)
+        if self.item_based:
+            return self.reconstruct(m.t().contiguous(), clamp).t().contiguous()
+        return self.reconstruct(m.contiguous(), clamp)
+
+    def recommend_topk(self, train_matrix, k=10, users=None, mask_seen=True, clamp=(1.0, 5.0)):
+        """Per-user top-k of the reconstruction, seen items pushed to -1e10 as helper.py:313.
+
+        Returns (item ids int32 [U,k], scores [U,k]); order: descending score, ascending item id on ties.
+        """
+        device = self._device_of(train_matrix)
+        m = train_matrix.to(device=device, dtype=torch.float32)
+        pred = self.reconstruct_all(m, clamp)
+        seen = (m > 0) if mask_seen else None
+        if users is not None:
+            users = torch.as_tensor(users, dtype=torch.int64, device=device)
+            pred = pred.index_select(0, users)
+            seen = seen.index_select(0, users) if seen is not None else None
+        return ops.topk_rows(pred, k, seen)
+
+    # -- N1: cached hidden layer for serving ------------------------------------------------------------------
+    def cache_hidden(self, train_matrix):
+        """H = sigmoid(encoder(X^T)) [items, hidden] for the item-based model; cached until weights change."""
+        if not self.item_based:
+            raise ValueError("cache_hidden is for the item-based model")
+        device = self._device_of(train_matrix)
+        sig, (we, be, wd, bd), extra = self._weights(device)
+        x = train_matrix.to(device=device, dtype=torch.float32).t().contiguous()
+        extra["H"] = ops.linear(x, we, be, act="sigmoid")
+        return extra["H"]
+
+    def predict_user(self, user_id, item_ids=None, clamp=(1.0, 5.0)):
+        """Scores of one user for all (or the given) items from the cached H: H . Wd[u] + bd[u].
+
+        Same numbers as inference_engine.py:266-272 (one full forward per item, keep column user_id).
+        """
+        hit = _dev_cache.get(self)
+        if hit is None or "H" not in hit[2]:
+            raise RuntimeError("call cache_hidden(train_matrix) first")
+        _, (we, be, wd, bd), extra = hit
+        if not 0 <= int(user_id) < wd.shape[0]:
+            raise IndexError("user id %d out of range [0, %d)" % (int(user_id), wd.shape[0]))
+        H = extra["H"]
+        if item_ids is not None:
+            idx = torch.as_tensor(item_ids, dtype=torch.int64, device=H.device)
+            H = ops.gather_rows(H, idx) if H.shape[1] % 4 == 0 else H.index_select(0, idx)
+        u = int(user_id)
+        act = (None, 0.0, 0.0) if clamp is None else ("clamp", float(clamp[0]), float(clamp[1]))
+        return ops.linear(H, wd[u:u + 1], bd[u:u + 1], act=act[0], lo=act[1], hi=act[2]).reshape(-1)

@@ -1,0 +1,371 @@
+// extern "C" surface of libreco_hip.so (declared in include/reco_hip.h): argument checking,
+// the packed tower handle, workspace carving and kernel sequencing.  No torch types, no hidden
+// allocation outside reco_tower_create, no synchronisation outside create / status.
+#include "reco_common.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+// launchers defined in tower.hip
+int tower_pack_image(const float* W2, const float* b2, const float* W3, const float* b3, const float* wp,
+                     int G, int has_l3, float* img, hipStream_t s);
+int tower_launch_tile(int G, int has_l3, const float* img, const float* P, const float* Q,
+                      const float* EUg, const float* EIg, const int64_t* users, const int64_t* cands,
+                      int64_t user_base, int64_t n_users, int64_t n_items, int64_t U, int64_t N,
+                      float* out, int64_t ld_out, float bp, int act, float lo, float hi, int32_t* oob,
+                      hipStream_t s);
+int tower_launch_pairs(int G, int has_l3, const float* img, const float* P, const float* Q,
+                       const float* EUg, const float* EIg, const int64_t* user, const int64_t* item,
+                       int64_t n_users, int64_t n_items, int64_t B, float* out, float bp, int act,
+                       float lo, float hi, int32_t* oob, hipStream_t s);
+int gmf_launch_pairs(const float* EUg, const float* EIg, const float* wp, const int64_t* user,
+                     const int64_t* item, int64_t n_users, int64_t n_items, int64_t B, int G, float* out,
+                     float bp, int act, float lo, float hi, int32_t* oob, hipStream_t s);
+int gmf_launch_tile(const float* EUg, const float* EIg, const float* wp, const int64_t* users,
+                    const int64_t* cands, int64_t user_base, int64_t n_users, int64_t n_items, int64_t U,
+                    int64_t N, int G, float* out, int64_t ld_out, float bp, int act, float lo, float hi,
+                    int32_t* oob, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void reco_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* reco_last_error(void) { return g_err; }
+extern "C" int reco_abi_version(void) { return 1; }
+
+// ---------------------------------------------------------------------------------------------
+// Linear / AutoRec
+// ---------------------------------------------------------------------------------------------
+extern "C" int reco_linear_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_t a_row_limit, int64_t M,
+                               const float* W, int64_t ldw, const float* bias, int64_t N, int64_t K,
+                               int act, float lo, float hi, float* C, int64_t ldc, void* stream)
+{
+    RECO_REQUIRE(act >= RECO_ACT_NONE && act <= RECO_ACT_RATING, "linear: unknown activation %d", act);
+    return launch_linear_f32(A, lda, a_rows, a_row_limit, M, W, ldw, bias, N, K, act, lo, hi, C, ldc, nullptr,
+                             (hipStream_t)stream);
+}
+
+extern "C" int reco_autorec_forward(const float* X, int64_t B, const float* We, const float* be,
+                                    const float* Wd, const float* bd, int64_t n_in, int64_t hidden,
+                                    int act, float lo, float hi, float* hidden_ws, float* out, void* stream)
+{
+    if (B <= 0) return RECO_OK;
+    RECO_REQUIRE(X && We && be && Wd && bd && hidden_ws && out, "autorec_forward: null pointer");
+    RECO_REQUIRE(n_in > 0 && hidden > 0, "autorec_forward: bad dimensions");
+    RECO_REQUIRE(act == RECO_ACT_NONE || act == RECO_ACT_CLAMP, "autorec_forward: act must be NONE or CLAMP");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = launch_linear_f32(X, n_in, nullptr, 0, B, We, n_in, be, hidden, n_in, RECO_ACT_SIGMOID, 0.f, 0.f,
+                               hidden_ws, hidden, nullptr, s);
+    if (rc) return rc;
+    return launch_linear_f32(hidden_ws, hidden, nullptr, 0, B, Wd, hidden, bd, n_in, hidden, act, lo, hi, out, n_in,
+                             nullptr, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// top-k
+// ---------------------------------------------------------------------------------------------
+extern "C" size_t reco_topk_workspace_bytes(int64_t rows, int64_t N, int k) { return topk_workspace_bytes(rows, N, k); }
+
+extern "C" int reco_topk_rows(const float* scores, int64_t rows, int64_t N, int64_t ld, int k,
+                              const uint8_t* exclude, int64_t ld_ex, int32_t* out_ids, float* out_vals,
+                              void* ws, size_t ws_bytes, void* stream)
+{
+    RECO_REQUIRE(ld >= N, "topk: ld smaller than N");
+    RECO_REQUIRE(!exclude || ld_ex >= N, "topk: ld_ex smaller than N");
+    return launch_topk_rows(scores, rows, N, ld, k, exclude, ld_ex, out_ids, out_vals, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// tower handle
+// ---------------------------------------------------------------------------------------------
+struct reco_tower {
+    reco_tower_desc_t d;
+    bool mfma;        // false: GMF-only model (no MLP branch)
+    int G;
+    int has_l3;
+    float bp;
+    float* img;       // packed weight image [IMG_SIZE]
+    float* P;         // [n_users,128] layer-1 user projection (+ b1)
+    float* Q;         // [n_items,128] layer-1 item projection
+    int32_t* oob;     // device counter of clamped ids
+    int device;
+};
+
+static int tower_project(const reco_tower* t, const float* u_rows, const int64_t* u_idx, int64_t u_limit, int64_t U,
+                         const float* i_rows, const int64_t* i_idx, int64_t i_limit, int64_t N,
+                         float* P, float* Q, hipStream_t s)
+{
+    const int dm = t->d.dm;
+    if (U > 0) {
+        int rc = launch_linear_f32(u_rows, dm, u_idx, u_limit, U, t->d.W[0], 2 * dm, t->d.b[0], H1, dm, RECO_ACT_NONE,
+                                   0.f, 0.f, P, H1, t->oob, s);
+        if (rc) return rc;
+    }
+    if (N > 0) {
+        int rc = launch_linear_f32(i_rows, dm, i_idx, i_limit, N, t->d.W[0] + dm, 2 * dm, nullptr, H1, dm,
+                                   RECO_ACT_NONE, 0.f, 0.f, Q, H1, t->oob, s);
+        if (rc) return rc;
+    }
+    return RECO_OK;
+}
+
+extern "C" void reco_tower_destroy(reco_tower_t* t)
+{
+    if (!t) return;
+    (void)hipFree(t->img);
+    (void)hipFree(t->P);
+    (void)hipFree(t->Q);
+    (void)hipFree(t->oob);
+    delete t;
+}
+
+extern "C" int reco_tower_create(const reco_tower_desc_t* d, void* stream, reco_tower_t** out)
+{
+    RECO_REQUIRE(d && out, "tower_create: null argument");
+    *out = nullptr;
+    RECO_REQUIRE(d->dg >= 0 && d->dm >= 0 && (d->dg > 0 || d->dm > 0), "tower_create: model has neither GMF nor MLP branch");
+    RECO_REQUIRE(d->dg % 4 == 0 && d->dm % 4 == 0, "tower_create: dg=%d / dm=%d must be multiples of 4", d->dg, d->dm);
+    RECO_REQUIRE(d->n_users >= 0 && d->n_items >= 0, "tower_create: negative table size");
+    RECO_REQUIRE(d->w_predict && d->b_predict, "tower_create: predict layer missing");
+    RECO_REQUIRE(d->act == RECO_ACT_NONE || d->act == RECO_ACT_RATING, "tower_create: act must be NONE or RATING");
+    const bool tables = d->n_users > 0 && d->n_items > 0;
+    if (tables && d->dg > 0) RECO_REQUIRE(d->user_gmf && d->item_gmf, "tower_create: GMF tables missing");
+    if (tables && d->dm > 0) RECO_REQUIRE(d->user_mlp && d->item_mlp, "tower_create: MLP tables missing");
+
+    hipStream_t s = (hipStream_t)stream;
+    reco_tower* t = new (std::nothrow) reco_tower();
+    if (!t) { reco_set_error("tower_create: out of host memory"); return RECO_ENOMEM; }
+    t->d = *d;
+    t->mfma = d->dm > 0;
+    t->G = d->dg;
+    t->has_l3 = d->n_layers == 3;
+    RECO_CHECK_HIP(hipGetDevice(&t->device));
+
+    if (t->mfma) {
+        const bool neumf = d->n_layers == 3 && d->layer_out[0] == H1 && d->layer_out[1] == H2 && d->layer_out[2] == H3 &&
+                           (d->dg == 32 || d->dg == 0);
+        const bool hybrid = d->n_layers == 2 && d->layer_out[0] == H1 && d->layer_out[1] == H2 && d->dg == 64;
+        if (!neumf && !hybrid) {
+            reco_set_error("tower_create: unsupported tower (dg=%d dm=%d layers=%d widths %d/%d/%d); the MFMA path covers "
+                           "NeuMF/MLP factor 32 x 3 layers (2*dm->128->64->32, dg in {0,32}) and the Hybrid head (2*dm->128->64, dg=64)",
+                           d->dg, d->dm, d->n_layers, d->layer_out[0], d->layer_out[1], d->layer_out[2]);
+            delete t;
+            return RECO_EINVAL;
+        }
+        for (int l = 0; l < d->n_layers; ++l)
+            if (!d->W[l] || !d->b[l]) { reco_set_error("tower_create: layer %d weights missing", l); delete t; return RECO_EINVAL; }
+    }
+
+    int rc = RECO_OK;
+    hipError_t e = hipMalloc(&t->oob, 256);
+    if (e == hipSuccess) e = hipMemsetAsync(t->oob, 0, 256, s);
+    if (e == hipSuccess && t->mfma) e = hipMalloc(&t->img, IMG_SIZE * sizeof(float));
+    if (e == hipSuccess && t->mfma && tables) e = hipMalloc(&t->P, (size_t)d->n_users * H1 * sizeof(float));
+    if (e == hipSuccess && t->mfma && tables) e = hipMalloc(&t->Q, (size_t)d->n_items * H1 * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(&t->bp, d->b_predict, sizeof(float), hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) {
+        reco_set_error("tower_create: %s", hipGetErrorString(e));
+        reco_tower_destroy(t);
+        return e == hipErrorOutOfMemory ? RECO_ENOMEM : RECO_EHIP;
+    }
+    if (t->mfma) {
+        rc = tower_pack_image(d->W[1], d->b[1], t->has_l3 ? d->W[2] : nullptr, t->has_l3 ? d->b[2] : nullptr,
+                              d->w_predict, t->G, t->has_l3, t->img, s);
+        if (!rc && tables)
+            rc = tower_project(t, d->user_mlp, nullptr, 0, d->n_users, d->item_mlp, nullptr, 0, d->n_items, t->P, t->Q, s);
+    }
+    if (!rc) {
+        e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { reco_set_error("tower_create: %s", hipGetErrorString(e)); rc = RECO_EHIP; }
+    }
+    if (rc) { reco_tower_destroy(t); return rc; }
+    *out = t;
+    return RECO_OK;
+}
+
+extern "C" int64_t reco_tower_status(reco_tower_t* t, void* stream)
+{
+    if (!t) return 0;
+    int32_t n = 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemcpyAsync(&n, t->oob, sizeof(n), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+    if (hipStreamSynchronize(s) != hipSuccess) return -1;
+    if (n != 0 && hipMemsetAsync(t->oob, 0, sizeof(int32_t), s) != hipSuccess) return -1;
+    return n;
+}
+
+extern "C" int reco_tower_score_pairs(reco_tower_t* t, const int64_t* user, const int64_t* item, int64_t B,
+                                      float* out, void* stream)
+{
+    RECO_REQUIRE(t, "score_pairs: null handle");
+    if (B <= 0) return RECO_OK;
+    RECO_REQUIRE(user && item && out, "score_pairs: null pointer");
+    RECO_REQUIRE(t->d.n_users > 0 && t->d.n_items > 0, "score_pairs: handle was created without embedding tables");
+    hipStream_t s = (hipStream_t)stream;
+    const reco_tower_desc_t& d = t->d;
+    if (!t->mfma)
+        return gmf_launch_pairs(d.user_gmf, d.item_gmf, d.w_predict, user, item, d.n_users, d.n_items, B, d.dg, out,
+                                t->bp, d.act, d.lo, d.hi, t->oob, s);
+    return tower_launch_pairs(t->G, t->has_l3, t->img, t->P, t->Q, d.user_gmf, d.item_gmf, user, item, d.n_users,
+                              d.n_items, B, out, t->bp, d.act, d.lo, d.hi, t->oob, s);
+}
+
+extern "C" size_t reco_tower_rows_workspace_bytes(int64_t B)
+{
+    return B > 0 ? 2 * align_up((size_t)B * H1 * sizeof(float), 256) : 0;
+}
+
+extern "C" int reco_tower_score_rows(reco_tower_t* t, const float* u_gmf, const float* i_gmf,
+                                     const float* u_mlp, const float* i_mlp, int64_t B, float* out,
+                                     void* ws, size_t ws_bytes, void* stream)
+{
+    RECO_REQUIRE(t, "score_rows: null handle");
+    if (B <= 0) return RECO_OK;
+    RECO_REQUIRE(out, "score_rows: null output");
+    hipStream_t s = (hipStream_t)stream;
+    const reco_tower_desc_t& d = t->d;
+    if (d.dg > 0) RECO_REQUIRE(u_gmf && i_gmf, "score_rows: GMF rows missing");
+    if (!t->mfma)
+        return gmf_launch_pairs(u_gmf, i_gmf, d.w_predict, nullptr, nullptr, B, B, B, d.dg, out, t->bp, d.act, d.lo,
+                                d.hi, nullptr, s);
+    RECO_REQUIRE(u_mlp && i_mlp, "score_rows: MLP rows missing");
+    const size_t half = align_up((size_t)B * H1 * sizeof(float), 256);
+    if (!ws || ws_bytes < 2 * half) { reco_set_error("score_rows: workspace too small (%zu < %zu)", ws_bytes, 2 * half); return RECO_ENOMEM; }
+    float* P = static_cast<float*>(ws);
+    float* Q = reinterpret_cast<float*>(static_cast<char*>(ws) + half);
+    int rc = tower_project(t, u_mlp, nullptr, 0, B, i_mlp, nullptr, 0, B, P, Q, s);
+    if (rc) return rc;
+    return tower_launch_pairs(t->G, t->has_l3, t->img, P, Q, u_gmf, i_gmf, nullptr, nullptr, B, B, B, out, t->bp,
+                              d.act, d.lo, d.hi, nullptr, s);
+}
+
+// ---- matrix / top-k forms ----------------------------------------------------------------------
+static size_t proj_bytes(int64_t rows) { return align_up((size_t)(rows > 0 ? rows : 0) * H1 * sizeof(float), 256); }
+
+extern "C" size_t reco_tower_matrix_workspace_bytes(int64_t U, int64_t N) { return proj_bytes(U) + proj_bytes(N); }
+
+static int score_matrix_impl(reco_tower* t, const int64_t* users, int64_t user_base, int64_t U,
+                             const int64_t* cands, int64_t N, const float* Qready, float* out, int64_t ld_out,
+                             float* P, float* Q, hipStream_t s)
+{
+    const reco_tower_desc_t& d = t->d;
+    if (!t->mfma)
+        return gmf_launch_tile(d.user_gmf, d.item_gmf, d.w_predict, users, cands, user_base, d.n_users, d.n_items, U, N,
+                               d.dg, out, ld_out, t->bp, d.act, d.lo, d.hi, t->oob, s);
+    // layer-1 projections for exactly these users / candidates, inside the call
+    const float* urows = users ? d.user_mlp : d.user_mlp + user_base * d.dm;
+    int rc = tower_project(t, urows, users, d.n_users, U, d.item_mlp, cands, d.n_items, Qready ? 0 : N, P, Q, s);
+    if (rc) return rc;
+    return tower_launch_tile(t->G, t->has_l3, t->img, P, Qready ? Qready : Q, d.user_gmf, d.item_gmf, users, cands,
+                             user_base, d.n_users, d.n_items, U, N, out, ld_out, t->bp, d.act, d.lo, d.hi, t->oob, s);
+}
+
+static int check_ranges(const reco_tower* t, const int64_t* users, int64_t user_base, int64_t U, const int64_t* cands,
+                        int64_t N, const char* who)
+{
+    RECO_REQUIRE(t->d.n_users > 0 && t->d.n_items > 0, "%s: handle was created without embedding tables", who);
+    if (!users) RECO_REQUIRE(user_base >= 0 && user_base + U <= t->d.n_users, "%s: user range [%lld, %lld) outside [0, %lld)",
+                             who, (long long)user_base, (long long)(user_base + U), (long long)t->d.n_users);
+    if (!cands) RECO_REQUIRE(N <= t->d.n_items, "%s: N=%lld exceeds the catalog (%lld items)", who, (long long)N,
+                             (long long)t->d.n_items);
+    return RECO_OK;
+}
+
+extern "C" int reco_tower_score_matrix(reco_tower_t* t, const int64_t* users, int64_t user_base, int64_t U,
+                                       const int64_t* cands, int64_t N, float* out, int64_t ld_out,
+                                       void* ws, size_t ws_bytes, void* stream)
+{
+    RECO_REQUIRE(t, "score_matrix: null handle");
+    if (U <= 0 || N <= 0) return RECO_OK;
+    RECO_REQUIRE(out && ld_out >= N, "score_matrix: bad output");
+    int rc = check_ranges(t, users, user_base, U, cands, N, "score_matrix");
+    if (rc) return rc;
+    float *P = nullptr, *Q = nullptr;
+    if (t->mfma) {
+        const size_t need = proj_bytes(U) + proj_bytes(N);
+        if (!ws || ws_bytes < need) { reco_set_error("score_matrix: workspace too small (%zu < %zu)", ws_bytes, need); return RECO_ENOMEM; }
+        P = static_cast<float*>(ws);
+        Q = reinterpret_cast<float*>(static_cast<char*>(ws) + proj_bytes(U));
+    }
+    return score_matrix_impl(t, users, user_base, U, cands, N, nullptr, out, ld_out, P, Q, (hipStream_t)stream);
+}
+
+// user-chunk size for the fused score + top-k path
+static const size_t kScoreChunkBytes = (size_t)1 << 30;   // ~1 GiB of score rows per chunk
+static const int64_t kTopkExtraRows = 8192;               // bound of rows*splits - rows in topk.hip choose_splits
+
+static int64_t default_chunk(int64_t U, int64_t N)
+{
+    int64_t c = (int64_t)(kScoreChunkBytes / ((size_t)N * sizeof(float)));
+    if (c < 32) c = 32;
+    return c < U ? c : U;
+}
+
+static size_t topk_chunk_bytes(int64_t Uc, int64_t N, int k)
+{
+    return proj_bytes(N) + proj_bytes(Uc) + align_up((size_t)Uc * N * sizeof(float), 256) +
+           align_up((size_t)(Uc + kTopkExtraRows) * k * sizeof(uint64_t), 256);
+}
+
+extern "C" size_t reco_tower_topk_workspace_bytes(int64_t U, int64_t N, int k)
+{
+    if (U <= 0 || N <= 0 || k <= 0) return 0;
+    return topk_chunk_bytes(default_chunk(U, N), N, k);
+}
+
+extern "C" int reco_tower_score_topk(reco_tower_t* t, const int64_t* users, int64_t user_base, int64_t U,
+                                     const int64_t* cands, int64_t N, int k,
+                                     const uint8_t* exclude, int64_t ld_ex,
+                                     int32_t* out_ids, float* out_scores,
+                                     void* ws, size_t ws_bytes, void* stream)
+{
+    RECO_REQUIRE(t, "score_topk: null handle");
+    if (U <= 0) return RECO_OK;
+    RECO_REQUIRE(out_ids && out_scores, "score_topk: null output");
+    RECO_REQUIRE(k >= 1 && k <= 128, "score_topk: k must be in [1,128], got %d", k);
+    RECO_REQUIRE(N >= k, "score_topk: k=%d exceeds the number of candidates %lld", k, (long long)N);
+    RECO_REQUIRE(!exclude || ld_ex >= N, "score_topk: ld_ex smaller than N");
+    int rc = check_ranges(t, users, user_base, U, cands, N, "score_topk");
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+
+    // largest user chunk the workspace admits
+    int64_t Uc = default_chunk(U, N);
+    while (Uc > 1 && topk_chunk_bytes(Uc, N, k) > ws_bytes) Uc = Uc / 2;
+    if (!ws || topk_chunk_bytes(Uc, N, k) > ws_bytes) {
+        reco_set_error("score_topk: workspace too small (%zu bytes; one user needs %zu)", ws_bytes, topk_chunk_bytes(1, N, k));
+        return RECO_ENOMEM;
+    }
+    char* w = static_cast<char*>(ws);
+    float* Q = reinterpret_cast<float*>(w); w += proj_bytes(N);
+    float* P = reinterpret_cast<float*>(w); w += proj_bytes(Uc);
+    float* scores = reinterpret_cast<float*>(w); w += align_up((size_t)Uc * N * sizeof(float), 256);
+    void* tws = w;
+    const size_t tws_bytes = align_up((size_t)(Uc + kTopkExtraRows) * k * sizeof(uint64_t), 256);
+
+    const reco_tower_desc_t& d = t->d;
+    if (t->mfma) {   // item-side projection once per call
+        rc = tower_project(t, nullptr, nullptr, 0, 0, d.item_mlp, cands, d.n_items, N, nullptr, Q, s);
+        if (rc) return rc;
+    }
+    for (int64_t c0 = 0; c0 < U; c0 += Uc) {
+        const int64_t n = U - c0 < Uc ? U - c0 : Uc;
+        rc = score_matrix_impl(t, users ? users + c0 : nullptr, user_base + c0, n, cands, N, Q, scores, N, P, Q, s);
+        if (rc) return rc;
+        rc = launch_topk_rows(scores, n, N, N, k, exclude ? exclude + c0 * ld_ex : nullptr, ld_ex, out_ids + c0 * k,
+                              out_scores + c0 * k, tws, tws_bytes, s);
+        if (rc) return rc;
+    }
+    return RECO_OK;
+}

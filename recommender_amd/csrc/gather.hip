@@ -1,0 +1,118 @@
+// K-a: embedding row gathers, gfx950.  HBM-bound: 8 + 8 D bytes per row (id + row read + row write).
+//
+// Replaces nn.Embedding.__call__ / mul / cat      src/helpers/ncf_model.py:207-211,220-224
+//
+// A row of D floats is moved by D/4 consecutive lanes as float4, so a wave instruction touches
+// whole 128-B lines of at most 64 / (D/4) rows (D = 32: 8 rows x 128 B; D = 128: 2 rows x 512 B)
+// and the write side is fully coalesced.  Ids are read once per row group and broadcast with
+// readlane-free arithmetic (each lane loads its own row's id; the 8/32 lanes of a row hit one
+// address, which the TA coalesces).  The scoring kernels in tower.hip gather straight into LDS;
+// these stand-alone forms exist for callers that need the materialised tensors and for the
+// HBM-roofline measurement of the gather itself.
+#include "reco_common.h"
+
+namespace {
+
+__device__ __forceinline__ int64_t clamp_row(int64_t id, int64_t n, int32_t* oob, bool count)
+{
+    if (id < 0 || id >= n) {
+        if (oob && count) atomicAdd(oob, 1);
+        return id < 0 ? 0 : n - 1;
+    }
+    return id;
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, int64_t rows, int dim4,
+                                                          const int64_t* __restrict__ idx, int64_t B,
+                                                          float* __restrict__ out, int32_t* oob)
+{
+    const int64_t total = B * dim4;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t b = t / dim4;
+        const int c = (int)(t - b * dim4);
+        const int64_t r = clamp_row(idx[b], rows, oob, c == 0);
+        reinterpret_cast<f32x4*>(out)[t] = reinterpret_cast<const f32x4*>(table)[r * dim4 + c];
+    }
+}
+
+struct FusedArgs {
+    const float* Eu_g; const float* Ei_g; const float* Eu_m; const float* Ei_m;
+    int64_t n_users, n_items;
+    int g4, m4;                  // float4 per GMF row / per MLP row
+    const int64_t* user; const int64_t* item;
+    int64_t B;
+    float* gmf_prod; float* mlp_in;
+    int32_t* oob;
+};
+
+// per pair: g4 float4 of gmf product + 2*m4 float4 of [user | item] MLP rows; work items are laid
+// out so that consecutive lanes write consecutive float4 of the outputs.
+__global__ __launch_bounds__(256) void neumf_gather_kernel(FusedArgs a)
+{
+    const int per_pair = (a.mlp_in ? 2 * a.m4 : 0);
+    if (a.mlp_in) {
+        const int64_t total = a.B * per_pair;
+        for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+            const int64_t b = t / per_pair;
+            const int c = (int)(t - b * per_pair);
+            f32x4 v;
+            if (c < a.m4) {
+                const int64_t u = clamp_row(a.user[b], a.n_users, a.oob, c == 0);
+                v = reinterpret_cast<const f32x4*>(a.Eu_m)[u * a.m4 + c];
+            } else {
+                const int64_t i = clamp_row(a.item[b], a.n_items, a.oob, c == a.m4);
+                v = reinterpret_cast<const f32x4*>(a.Ei_m)[i * a.m4 + (c - a.m4)];
+            }
+            reinterpret_cast<f32x4*>(a.mlp_in)[t] = v;
+        }
+    }
+    if (a.gmf_prod) {
+        const int64_t total = a.B * a.g4;
+        for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+            const int64_t b = t / a.g4;
+            const int c = (int)(t - b * a.g4);
+            const int64_t u = clamp_row(a.user[b], a.n_users, a.oob, c == 0 && !a.mlp_in);
+            const int64_t i = clamp_row(a.item[b], a.n_items, a.oob, c == 0 && !a.mlp_in);
+            reinterpret_cast<f32x4*>(a.gmf_prod)[t] =
+                reinterpret_cast<const f32x4*>(a.Eu_g)[u * a.g4 + c] * reinterpret_cast<const f32x4*>(a.Ei_g)[i * a.g4 + c];
+        }
+    }
+}
+
+unsigned stream_grid(int64_t work_items)
+{
+    const int64_t blocks = ceil_div64(work_items, 256);
+    return (unsigned)(blocks < 256 * 16 ? (blocks > 0 ? blocks : 1) : 256 * 16);
+}
+
+}  // namespace
+
+extern "C" int reco_gather_rows(const float* table, int64_t rows, int dim, const int64_t* idx, int64_t B,
+                                float* out, int32_t* oob, void* stream)
+{
+    if (B <= 0) return RECO_OK;
+    RECO_REQUIRE(table && idx && out, "gather_rows: null pointer");
+    RECO_REQUIRE(dim > 0 && dim % 4 == 0, "gather_rows: dim must be a positive multiple of 4, got %d", dim);
+    RECO_REQUIRE(rows > 0, "gather_rows: empty table");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(stream_grid(B * (dim / 4))), dim3(256), 0, (hipStream_t)stream,
+                       table, rows, dim / 4, idx, B, out, oob);
+    RECO_CHECK_LAUNCH();
+    return RECO_OK;
+}
+
+extern "C" int reco_neumf_gather(const float* Eu_g, const float* Ei_g, const float* Eu_m, const float* Ei_m,
+                                 int64_t n_users, int64_t n_items, int dg, int dm,
+                                 const int64_t* user, const int64_t* item, int64_t B,
+                                 float* gmf_prod, float* mlp_in, int32_t* oob, void* stream)
+{
+    if (B <= 0) return RECO_OK;
+    RECO_REQUIRE(user && item, "neumf_gather: null id pointer");
+    RECO_REQUIRE(!gmf_prod || (Eu_g && Ei_g && dg > 0 && dg % 4 == 0), "neumf_gather: bad GMF tables / dg=%d", dg);
+    RECO_REQUIRE(!mlp_in || (Eu_m && Ei_m && dm > 0 && dm % 4 == 0), "neumf_gather: bad MLP tables / dm=%d", dm);
+    RECO_REQUIRE(n_users > 0 && n_items > 0, "neumf_gather: empty tables");
+    FusedArgs a{Eu_g, Ei_g, Eu_m, Ei_m, n_users, n_items, dg / 4, dm / 4, user, item, B, gmf_prod, mlp_in, oob};
+    const int64_t work = B * (mlp_in ? 2 * (dm / 4) : dg / 4);
+    hipLaunchKernelGGL(neumf_gather_kernel, dim3(stream_grid(work)), dim3(256), 0, (hipStream_t)stream, a);
+    RECO_CHECK_LAUNCH();
+    return RECO_OK;
+}

@@ -1,0 +1,61 @@
+// Shared declarations for the gfx950 scoring engine (internal; the public C ABI is include/reco_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/reco_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void reco_set_error(const char* fmt, ...);
+
+#define RECO_CHECK_HIP(expr)                                                                        \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            reco_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return RECO_EHIP;                                                                       \
+        }                                                                                           \
+    } while (0)
+
+#define RECO_REQUIRE(cond, ...)          \
+    do {                                 \
+        if (!(cond)) {                   \
+            reco_set_error(__VA_ARGS__); \
+            return RECO_EINVAL;          \
+        }                                \
+    } while (0)
+
+#define RECO_CHECK_LAUNCH() RECO_CHECK_HIP(hipGetLastError())
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- tower geometry (fixed by the reference's shipped configs) -------------------------------
+// layer 1 (factorised into P/Q) -> H1 = 128; layer 2: 128 -> 64 (MFMA); layer 3: 64 -> 32 (MFMA, NeuMF only)
+constexpr int H1 = 128;
+constexpr int H2 = 64;
+constexpr int H3 = 32;
+
+// Packed weight image, in floats.  Laid out so that every MFMA A-operand fetch is one conflict-free
+// ds_read_b128 at ((block * 64 + lane) * 4): see tower.hip pack_image_kernel for the index maps.
+constexpr int IMG_W2 = 0;                    // [t(2)][q(16)][lane(64)][4]
+constexpr int IMG_W3 = IMG_W2 + 2 * 16 * 256;  // [q'(8)][lane(64)][4]
+constexpr int IMG_B2 = IMG_W3 + 8 * 256;      // [t(2)][rq(4)][h(2)][4]
+constexpr int IMG_B3 = IMG_B2 + 64;           // [rq(4)][h(2)][4]
+constexpr int IMG_WPM = IMG_B3 + 32;          // predict weights, MLP half, in accumulator order (32 or 64)
+constexpr int IMG_WPG = IMG_WPM + 64;         // predict weights, GMF half [G]
+constexpr int IMG_SIZE = IMG_WPG + 64;        // 10464 floats = 41,856 B
+
+// internal launchers (defined in the .hip files, called from api.hip)
+struct TowerImage;  // opaque here
+
+int launch_linear_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_t a_row_limit, int64_t M,
+                      const float* W, int64_t ldw, const float* bias, int64_t N, int64_t K,
+                      int act, float lo, float hi, float* C, int64_t ldc, int32_t* oob, hipStream_t s);
+
+int launch_topk_rows(const float* scores, int64_t rows, int64_t N, int64_t ld, int k,
+                     const uint8_t* exclude, int64_t ld_ex, int32_t* out_ids, float* out_vals,
+                     void* ws, size_t ws_bytes, hipStream_t s);
+size_t topk_workspace_bytes(int64_t rows, int64_t N, int k);

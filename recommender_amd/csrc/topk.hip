@@ -1,0 +1,253 @@
+// K-d: wavefront-level per-row top-k select, gfx950.
+//
+// Replaces the reference's full sorts for K << N:
+//   np.argsort(scores)[::-1][:k]        src/api/core/inference_engine.py:166
+//   torch.topk(pred, 10) + torch.take   src/ncf/ncf.ipynb cell 8
+//   np.argsort(p)[-k:][::-1]            src/autorec/utils/helper.py:335
+//   list.sort(reverse=True)[:k]         src/api/core/inference_engine.py:294,341
+// with the seen-item mask of helper.py:313 fused into the read.
+//
+// One wave streams one row segment with coalesced loads and keeps the best K (<= 128) candidates
+// SORTED IN REGISTERS, rank r in lane r & 63 (slot r >> 6).  Every element is turned into a 64-bit
+// key  (order-preserving float bits << 32) | ~position, so "descending score, ascending position
+// among equals" is a single unsigned compare and ties are deterministic.  An element
+// enters the list only if its key beats the current K-th key (one v_cmp + ballot per 64 elements in
+// the steady state: the kernel is HBM-bound, 4 N bytes per row).  Long rows are split over several
+// waves; a second launch merges the per-segment lists with the same insert.
+#include "reco_common.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ uint32_t float_key(float v)
+{
+    if (v != v) return 0xFFFFFFFFu;          // NaN ranks first (numpy sorts NaN last ascending; torch.topk: largest)
+    v += 0.f;                                // -0.0 -> +0.0 so that equal scores have equal keys
+    const uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ float key_float(uint32_t k)
+{
+    if (k == 0xFFFFFFFFu) return __uint_as_float(0x7FC00000u);
+    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+
+__device__ __forceinline__ u64 shfl_up1(u64 v, int lane)
+{
+    const int src = lane > 0 ? lane - 1 : 0;
+    const uint32_t lo = __shfl((uint32_t)v, src);
+    const uint32_t hi = __shfl((uint32_t)(v >> 32), src);
+    return ((u64)hi << 32) | lo;
+}
+
+__device__ __forceinline__ u64 bcast(u64 v, int src)
+{
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src);
+    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src);
+    return ((u64)hi << 32) | lo;
+}
+
+// Sorted (descending) list of 64 * SLOTS keys across the wave.  0 = empty.
+template <int SLOTS>
+struct WaveList {
+    u64 e[SLOTS];
+    __device__ __forceinline__ void clear()
+    {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) e[s] = 0;
+    }
+    // x is wave-uniform
+    __device__ __forceinline__ void insert(u64 x, int lane)
+    {
+        u64 carry = x;   // element entering slot s (at position pos, or at lane 0 when carried over)
+        bool placed = false;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            if (!placed) {
+                const int pos = __popcll(__ballot(e[s] > x));   // e[s] sorted descending: prefix of greater keys
+                if (pos < 64) {
+                    const u64 up = shfl_up1(e[s], lane);
+                    const u64 last = bcast(e[s], 63);
+                    e[s] = lane < pos ? e[s] : (lane == pos ? x : up);
+                    carry = last;
+                    placed = true;
+                }
+            } else {
+                const u64 up = shfl_up1(e[s], lane);
+                const u64 last = bcast(e[s], 63);
+                e[s] = lane == 0 ? carry : up;
+                carry = last;
+            }
+        }
+    }
+    __device__ __forceinline__ u64 kth(int k) const   // key at rank k-1 (wave-uniform)
+    {
+        u64 r = 0;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+            if (((k - 1) >> 6) == s) r = bcast(e[s], (k - 1) & 63);
+        return r;
+    }
+};
+
+template <int SLOTS>
+__device__ __forceinline__ void offer(WaveList<SLOTS>& L, u64 key, bool valid, u64& thr, int k, int lane)
+{
+    u64 m = __ballot(valid && key > thr);
+    while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        const u64 x = bcast(key, src);
+        m &= m - 1;
+        if (x > thr) {               // thr may have risen since the ballot
+            L.insert(x, lane);
+            thr = L.kth(k);
+        }
+    }
+}
+
+struct TopkArgs {
+    const float* scores;
+    int64_t rows, N, ld;
+    int k;
+    const uint8_t* exclude;
+    int64_t ld_ex;
+    int splits;
+    int64_t seg;            // elements per split (multiple of 64)
+    u64* partial;           // [rows][splits][k] when splits > 1
+    int32_t* out_ids;
+    float* out_vals;
+};
+
+template <int SLOTS>
+__global__ __launch_bounds__(256) void topk_scan_kernel(TopkArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= a.rows * a.splits) return;
+    const int64_t row = w / a.splits;
+    const int split = (int)(w % a.splits);
+    const int64_t s0 = split * a.seg;
+    const int64_t s1 = s0 + a.seg < a.N ? s0 + a.seg : a.N;
+    const float* src = a.scores + row * a.ld;
+    const uint8_t* ex = a.exclude ? a.exclude + row * a.ld_ex : nullptr;
+
+    WaveList<SLOTS> L;
+    L.clear();
+    u64 thr = 0;
+    for (int64_t base = s0; base < s1; base += 256) {
+        float v[4];
+        bool ok[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int64_t n = base + t * 64 + lane;
+            ok[t] = n < s1;
+            v[t] = ok[t] ? src[n] : 0.f;
+            if (ex && ok[t] && ex[n]) v[t] = v[t] * 0.f - 1e10f;   // helper.py:313: pred*(~seen) - seen*1e10
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int64_t n = base + t * 64 + lane;
+            const u64 key = ((u64)float_key(v[t]) << 32) | (uint32_t)~(uint32_t)n;
+            offer<SLOTS>(L, key, ok[t], thr, a.k, lane);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int r = s * 64 + lane;
+        if (r < a.k) {
+            if (a.splits > 1) {
+                a.partial[(row * a.splits + split) * a.k + r] = L.e[s];
+            } else {
+                a.out_ids[row * a.k + r] = (int32_t)~(uint32_t)L.e[s];
+                a.out_vals[row * a.k + r] = key_float((uint32_t)(L.e[s] >> 32));
+            }
+        }
+    }
+}
+
+template <int SLOTS>
+__global__ __launch_bounds__(256) void topk_merge_kernel(TopkArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const u64* src = a.partial + row * a.splits * a.k;
+    const int64_t n = (int64_t)a.splits * a.k;
+    WaveList<SLOTS> L;
+    L.clear();
+    u64 thr = 0;
+    for (int64_t base = 0; base < n; base += 64) {
+        const bool ok = base + lane < n;
+        const u64 key = ok ? src[base + lane] : 0;
+        offer<SLOTS>(L, key, ok && key != 0, thr, a.k, lane);
+    }
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int r = s * 64 + lane;
+        if (r < a.k) {
+            a.out_ids[row * a.k + r] = (int32_t)~(uint32_t)L.e[s];
+            a.out_vals[row * a.k + r] = key_float((uint32_t)(L.e[s] >> 32));
+        }
+    }
+}
+
+int choose_splits(int64_t rows, int64_t N, int k)
+{
+    // aim for >= 8192 waves (256 CUs x 32) while keeping segments long enough to amortise the list
+    int64_t want = ceil_div64(8192, rows);
+    int64_t max_by_len = N / 4096 > 0 ? N / 4096 : 1;
+    int64_t s = want < max_by_len ? want : max_by_len;
+    if (s < 1) s = 1;
+    if (s > 1024) s = 1024;
+    (void)k;
+    return (int)s;
+}
+
+}  // namespace
+
+size_t topk_workspace_bytes(int64_t rows, int64_t N, int k)
+{
+    const int splits = choose_splits(rows, N, k);
+    return splits > 1 ? align_up((size_t)rows * splits * k * sizeof(u64), 256) : 0;
+}
+
+int launch_topk_rows(const float* scores, int64_t rows, int64_t N, int64_t ld, int k,
+                     const uint8_t* exclude, int64_t ld_ex, int32_t* out_ids, float* out_vals,
+                     void* ws, size_t ws_bytes, hipStream_t s)
+{
+    if (rows <= 0) return RECO_OK;
+    RECO_REQUIRE(k >= 1 && k <= 128, "topk: k must be in [1,128], got %d", k);
+    RECO_REQUIRE(N >= k, "topk: k=%d exceeds the number of candidates %lld", k, (long long)N);
+    RECO_REQUIRE(N < (1ll << 32) - 1, "topk: row too long");
+    RECO_REQUIRE(scores && out_ids && out_vals, "topk: null pointer");
+    TopkArgs a{scores, rows, N, ld, k, exclude, ld_ex, 1, 0, nullptr, out_ids, out_vals};
+    a.splits = choose_splits(rows, N, k);
+    if (a.splits > 1) {
+        const size_t need = (size_t)rows * a.splits * k * sizeof(u64);
+        if (ws == nullptr || ws_bytes < need) {
+            reco_set_error("topk: workspace too small (%zu < %zu bytes)", ws_bytes, need);
+            return RECO_ENOMEM;
+        }
+        a.partial = static_cast<u64*>(ws);
+    }
+    a.seg = ceil_div64(ceil_div64(N, a.splits), 64) * 64;
+    const int64_t waves = rows * a.splits;
+    const int64_t blocks = ceil_div64(waves, 4);
+    RECO_REQUIRE(blocks < (1ll << 31), "topk grid too large");
+    if (k <= 64)
+        hipLaunchKernelGGL(topk_scan_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(topk_scan_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    RECO_CHECK_LAUNCH();
+    if (a.splits > 1) {
+        const int64_t mblocks = ceil_div64(rows, 4);
+        if (k <= 64)
+            hipLaunchKernelGGL(topk_merge_kernel<1>, dim3((unsigned)mblocks), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL(topk_merge_kernel<2>, dim3((unsigned)mblocks), dim3(256), 0, s, a);
+        RECO_CHECK_LAUNCH();
+    }
+    return RECO_OK;
+}

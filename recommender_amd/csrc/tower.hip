@@ -1,0 +1,588 @@
+// K-b: the fused scoring tower for gfx950 (MI355X), fp32 MFMA.
+//
+// Replaces, per (user, item) pair, the reference's chain
+//   4x Embedding -> mul -> cat -> [Linear, ReLU] x3 -> cat -> Linear        src/helpers/ncf_model.py:205-249
+// and the Hybrid head  mul -> cat -> [Linear, ReLU] x2 -> cat -> Linear     src/hybridautorecncf/evaluate_hybridautorecncf_rating.py:167-184
+//
+// Math.  Layer 1 acts on a concatenation, so it splits exactly:
+//   W1 [eu | ei] + b1 = (W1[:, :dm] eu + b1) + W1[:, dm:] ei = P[u] + Q[i]
+// P and Q are per-user / per-item 128-vectors (computed by the GEMM kernel in gemm.hip); per pair
+// layer 1 is then add + ReLU.  Layers 2 (128->64) and 3 (64->32) run on v_mfma_f32_32x32x2_f32 with
+// the PAIR on the MFMA column (lane & 31) and the FEATURE on the accumulator rows, so the 32x32
+// accumulator of layer 2 is, register for register, the B operand of layer 3: nothing moves
+// between layers, no LDS round trip, no HBM traffic.  Per 32 pairs a wave issues 128 + 32 MFMAs.
+//
+// MFMA operand maps (guide section 3):  A: lane l holds A[i = l & 31][kslot = l >> 5]
+//                                       B: lane l holds B[kslot = l >> 5][j = l & 31]
+//                                       D: lane l reg r holds D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31]
+// The k index carried by (step, kslot) is free as long as A and B agree; we pick it so that each
+// lane's operands for 4 consecutive steps are 16 contiguous bytes (one ds_read_b128 / one float4):
+//   layer 2, quad q (0..15), step jj (0..3), half h:   k = 8 q + 4 h + jj
+//   layer 3, quad q' (0..7), step jj, half h:           k = 32 (q' >> 2) + 8 (q' & 3) + 4 h + jj
+//                                                      (= the feature held by acc[q' >> 2][4 (q' & 3) + jj])
+#include "reco_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// weight image packing
+// ---------------------------------------------------------------------------------------------
+struct PackArgs {
+    const float* W2;   // [64,128]
+    const float* b2;   // [64]
+    const float* W3;   // [32,64] or null
+    const float* b3;   // [32] or null
+    const float* wp;   // [G + mlp_out]
+    int G;
+    int has_l3;
+};
+
+__global__ void pack_image_kernel(PackArgs a, float* __restrict__ img)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= IMG_SIZE) return;
+    float v = 0.f;
+    if (idx < IMG_W3) {  // W2 image [t][q][lane][jj]
+        const int e = idx - IMG_W2;
+        const int jj = e & 3, lane = (e >> 2) & 63, q = (e >> 8) & 15, t = e >> 12;
+        v = a.W2[(32 * t + (lane & 31)) * H1 + 8 * q + 4 * (lane >> 5) + jj];
+    } else if (idx < IMG_B2) {  // W3 image [q'][lane][jj]
+        if (a.has_l3) {
+            const int e = idx - IMG_W3;
+            const int jj = e & 3, lane = (e >> 2) & 63, q = e >> 8;
+            v = a.W3[(lane & 31) * H2 + 32 * (q >> 2) + 8 * (q & 3) + 4 * (lane >> 5) + jj];
+        }
+    } else if (idx < IMG_B3) {  // b2 in accumulator order [t][rq][h][jj]
+        const int e = idx - IMG_B2;
+        const int jj = e & 3, h = (e >> 2) & 1, rq = (e >> 3) & 3, t = e >> 5;
+        v = a.b2[32 * t + jj + 8 * rq + 4 * h];
+    } else if (idx < IMG_WPM) {  // b3 in accumulator order [rq][h][jj]
+        if (a.has_l3) {
+            const int e = idx - IMG_B3;
+            const int jj = e & 3, h = (e >> 2) & 1, rq = e >> 3;
+            v = a.b3[jj + 8 * rq + 4 * h];
+        }
+    } else if (idx < IMG_WPG) {  // predict weights of the MLP half, accumulator order
+        const int e = idx - IMG_WPM;
+        const int jj = e & 3, h = (e >> 2) & 1;
+        if (a.has_l3) {
+            if (e < 32) v = a.wp[a.G + jj + 8 * (e >> 3) + 4 * h];
+        } else {
+            const int rq = (e >> 3) & 3, t = e >> 5;
+            v = a.wp[a.G + 32 * t + jj + 8 * rq + 4 * h];
+        }
+    } else {  // predict weights of the GMF half
+        const int e = idx - IMG_WPG;
+        if (e < a.G) v = a.wp[e];
+    }
+    img[idx] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the per-group MFMA body, shared by the tile and the pair kernel
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 relu4(f32x4 v)
+{
+    f32x4 r;
+    r.x = fmaxf(v.x, 0.f); r.y = fmaxf(v.y, 0.f); r.z = fmaxf(v.z, 0.f); r.w = fmaxf(v.w, 0.f);
+    return r;
+}
+
+__device__ __forceinline__ f32x16 bias16(const float* s_b, int h)
+{
+    // accumulator register r = 4 rq + jj  <-  image [rq][h][jj]
+    f32x16 c;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(s_b + (rq * 2 + h) * 4);
+        c[4 * rq + 0] = v.x; c[4 * rq + 1] = v.y; c[4 * rq + 2] = v.z; c[4 * rq + 3] = v.w;
+    }
+    return c;
+}
+
+__device__ __forceinline__ float dot16_relu(const f32x16 acc, const float* s_w, int h, float part)
+{
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(s_w + (rq * 2 + h) * 4);
+        part = fmaf(w.x, fmaxf(acc[4 * rq + 0], 0.f), part);
+        part = fmaf(w.y, fmaxf(acc[4 * rq + 1], 0.f), part);
+        part = fmaf(w.z, fmaxf(acc[4 * rq + 2], 0.f), part);
+        part = fmaf(w.w, fmaxf(acc[4 * rq + 3], 0.f), part);
+    }
+    return part;
+}
+
+// Layers 2 (+3) and the MLP half of the predict layer for the 32 pairs of this wave.
+// x1(q) must return this lane's 4 layer-1 activations relu(P+Q)[8q + 4h .. 8q + 4h + 3] for its pair.
+template <bool L3, typename X1>
+__device__ __forceinline__ float tower_mlp_part(const float* s_img, int lane, X1 x1)
+{
+    const int h = lane >> 5;
+    f32x16 acc0 = bias16(s_img + IMG_B2, h);
+    f32x16 acc1 = bias16(s_img + IMG_B2 + 32, h);
+    const f32x4* w2 = reinterpret_cast<const f32x4*>(s_img + IMG_W2) + lane;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const f32x4 x = x1(q);
+        const f32x4 a0 = w2[q * 64];
+        const f32x4 a1 = w2[(16 + q) * 64];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, x.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, x.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, x.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, x.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, x.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, x.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, x.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, x.w, acc1, 0, 0, 0);
+    }
+    float part = 0.f;
+    if constexpr (L3) {
+        f32x16 acc3 = bias16(s_img + IMG_B3, h);
+        const f32x4* w3 = reinterpret_cast<const f32x4*>(s_img + IMG_W3) + lane;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 a = w3[q * 64];
+            const int r = 4 * (q & 3);
+            if (q < 4) {
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, fmaxf(acc0[r + 0], 0.f), acc3, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, fmaxf(acc0[r + 1], 0.f), acc3, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, fmaxf(acc0[r + 2], 0.f), acc3, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, fmaxf(acc0[r + 3], 0.f), acc3, 0, 0, 0);
+            } else {
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, fmaxf(acc1[r + 0], 0.f), acc3, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, fmaxf(acc1[r + 1], 0.f), acc3, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, fmaxf(acc1[r + 2], 0.f), acc3, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, fmaxf(acc1[r + 3], 0.f), acc3, 0, 0, 0);
+            }
+        }
+        part = dot16_relu(acc3, s_img + IMG_WPM, h, part);
+    } else {
+        part = dot16_relu(acc0, s_img + IMG_WPM, h, part);
+        part = dot16_relu(acc1, s_img + IMG_WPM + 32, h, part);
+    }
+    return part;
+}
+
+__device__ __forceinline__ float epilogue(float logit, int act, float lo, float hi)
+{
+    if (act == RECO_ACT_RATING) return (1.f / (1.f + __expf(-logit))) * (hi - lo) + lo;
+    return logit;
+}
+
+__device__ __forceinline__ int64_t clamp_id(int64_t id, int64_t n, int32_t* oob)
+{
+    if (id < 0 || id >= n) {
+        if (oob) atomicAdd(oob, 1);
+        return id < 0 ? 0 : n - 1;
+    }
+    return id;
+}
+
+// ---------------------------------------------------------------------------------------------
+// tile kernel: scores for (user chunk) x (item tile)
+// ---------------------------------------------------------------------------------------------
+constexpr int TI = 128;        // items per tile (4 MFMA column groups)
+constexpr int TUB = 32;        // users per block (4 per wave)
+constexpr int QS = H1 + 4;     // padded LDS row stride of the Q tile: conflict-free ds_read_b128 by 16 rows
+
+struct TileArgs {
+    const float* img;
+    const float* P;        // [U,128]  row u <-> users[u]
+    const float* Q;        // [N,128]  row n <-> cands[n]
+    const float* EUg;      // GMF user table
+    const float* EIg;      // GMF item table
+    const int64_t* users;  // nullable
+    const int64_t* cands;  // nullable
+    int64_t user_base, n_users, n_items;
+    int64_t U, N;
+    float* out;
+    int64_t ld_out;
+    float bp;
+    int act;
+    float lo, hi;
+    int32_t* oob;
+};
+
+template <int G, bool L3>
+__global__ __launch_bounds__(512, 2) void tower_tile_kernel(TileArgs a)
+{
+    constexpr int GS = G + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_img = smem;
+    float* s_q = smem + IMG_SIZE;
+    float* s_g = s_q + TI * QS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    const int64_t tiles_n = (a.N + TI - 1) / TI;
+    const int64_t n0 = (int64_t)(blockIdx.x % tiles_n) * TI;
+    const int64_t u0 = (int64_t)(blockIdx.x / tiles_n) * TUB;
+
+    for (int i = tid; i < IMG_SIZE / 4; i += 512)
+        reinterpret_cast<f32x4*>(s_img)[i] = reinterpret_cast<const f32x4*>(a.img)[i];
+    for (int i = tid; i < TI * (H1 / 4); i += 512) {
+        const int r = i >> 5, c = i & 31;
+        const int64_t n = n0 + r;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n < a.N) v = reinterpret_cast<const f32x4*>(a.Q + n * H1)[c];
+        *reinterpret_cast<f32x4*>(s_q + r * QS + c * 4) = v;
+    }
+    if constexpr (G > 0) {
+        for (int i = tid; i < TI * (G / 4); i += 512) {
+            const int r = i / (G / 4), c = i % (G / 4);
+            const int64_t n = n0 + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (n < a.N) {
+                const int64_t id = clamp_id(a.cands ? a.cands[n] : n, a.n_items, c == 0 && blockIdx.x < tiles_n ? a.oob : nullptr);
+                v = reinterpret_cast<const f32x4*>(a.EIg + id * G)[c];
+            }
+            *reinterpret_cast<f32x4*>(s_g + r * GS + c * 4) = v;
+        }
+    }
+    __syncthreads();
+
+    for (int uu = wave; uu < TUB; uu += 8) {
+        const int64_t u = u0 + uu;
+        if (u >= a.U) break;
+        f32x4 p[16];
+        const f32x4* prow = reinterpret_cast<const f32x4*>(a.P + u * H1 + 4 * h);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) p[q] = prow[2 * q];
+        f32x4 gu[G > 0 ? G / 8 : 1];
+        if constexpr (G > 0) {
+            const int64_t uid = clamp_id(a.users ? a.users[u] : a.user_base + u, a.n_users,
+                                         (lane == 0 && n0 == 0) ? a.oob : nullptr);
+            const f32x4* gr = reinterpret_cast<const f32x4*>(a.EUg + uid * G + h * (G / 2));
+#pragma unroll
+            for (int c = 0; c < G / 8; ++c) gu[c] = gr[c];
+        }
+#pragma unroll 1
+        for (int g = 0; g < TI / 32; ++g) {
+            // keep the (loop-invariant) weight-image reads inside the loop: hoisted, they would pin ~200 VGPRs
+            asm volatile("" ::: "memory");
+            const float* qrow = s_q + (g * 32 + j) * QS + 4 * h;
+            float part = tower_mlp_part<L3>(s_img, lane, [&](int q) {
+                const f32x4 qv = *reinterpret_cast<const f32x4*>(qrow + 8 * q);
+                return relu4(p[q] + qv);
+            });
+            if constexpr (G > 0) {
+                const float* grow = s_g + (g * 32 + j) * GS + h * (G / 2);
+                const float* wpg = s_img + IMG_WPG + h * (G / 2);
+#pragma unroll
+                for (int c = 0; c < G / 8; ++c) {
+                    const f32x4 gi = *reinterpret_cast<const f32x4*>(grow + 4 * c);
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(wpg + 4 * c);
+                    part = fmaf(gu[c].x * gi.x, w.x, part);
+                    part = fmaf(gu[c].y * gi.y, w.y, part);
+                    part = fmaf(gu[c].z * gi.z, w.z, part);
+                    part = fmaf(gu[c].w * gi.w, w.w, part);
+                }
+            }
+            const float total = part + __shfl_xor(part, 32) + a.bp;
+            const int64_t n = n0 + g * 32 + j;
+            if (h == 0 && n < a.N) a.out[u * a.ld_out + n] = epilogue(total, a.act, a.lo, a.hi);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pair kernel: forward(user[B], item[B])
+// ---------------------------------------------------------------------------------------------
+struct PairArgs {
+    const float* img;
+    const float* P;        // [n_users,128]
+    const float* Q;        // [n_items,128]
+    const float* EUg;
+    const float* EIg;
+    const int64_t* user;   // nullable: identity (row b of P / EUg)
+    const int64_t* item;   // nullable: identity
+    int64_t n_users, n_items, B;
+    float* out;
+    float bp;
+    int act;
+    float lo, hi;
+    int32_t* oob;
+};
+
+template <int G, bool L3>
+__global__ __launch_bounds__(256, 1) void tower_pairs_kernel(PairArgs a)
+{
+    constexpr int GS = G + 4;
+    constexpr int WAVE_FLOATS = 32 * QS + (G > 0 ? 32 * GS : 0);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_img = smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    float* s_x = smem + IMG_SIZE + wave * WAVE_FLOATS;   // [32][QS]  relu(P+Q) of this wave's pairs
+    float* s_gp = s_x + 32 * QS;                          // [32][GS]  gmf products
+
+    for (int i = tid; i < IMG_SIZE / 4; i += 256)
+        reinterpret_cast<f32x4*>(s_img)[i] = reinterpret_cast<const f32x4*>(a.img)[i];
+
+    const int64_t nchunks = (a.B + 127) / 128;
+    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int64_t base = chunk * 128 + wave * 32;
+        // ids of this wave's 32 pairs live in lanes 0..31
+        int64_t my_u = 0, my_i = 0;
+        {
+            const int64_t b = base + j;
+            if (b < a.B) {
+                my_u = clamp_id(a.user ? a.user[b] : b, a.n_users, h == 0 ? a.oob : nullptr);
+                my_i = clamp_id(a.item ? a.item[b] : b, a.n_items, h == 0 ? a.oob : nullptr);
+            }
+        }
+        __syncthreads();   // previous iteration's readers are done with s_x / s_gp (and the image is loaded)
+        // stage x1 = relu(P[u] + Q[i]): one wave instruction covers two whole 512-B rows
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int pl = it * 2 + h;
+            const int64_t u = __shfl(my_u, pl);
+            const int64_t i = __shfl(my_i, pl);
+            const f32x4 pv = reinterpret_cast<const f32x4*>(a.P + u * H1)[j];
+            const f32x4 qv = reinterpret_cast<const f32x4*>(a.Q + i * H1)[j];
+            *reinterpret_cast<f32x4*>(s_x + pl * QS + 4 * j) = relu4(pv + qv);
+        }
+        if constexpr (G > 0) {
+            constexpr int C = G / 4;                      // float4 per row
+#pragma unroll
+            for (int it = 0; it < (32 * C) / 64; ++it) {
+                const int e = it * 64 + lane;
+                const int pl = e / C, c = e % C;
+                const int64_t u = __shfl(my_u, pl);
+                const int64_t i = __shfl(my_i, pl);
+                const f32x4 gu = reinterpret_cast<const f32x4*>(a.EUg + u * G)[c];
+                const f32x4 gi = reinterpret_cast<const f32x4*>(a.EIg + i * G)[c];
+                *reinterpret_cast<f32x4*>(s_gp + pl * GS + 4 * c) = gu * gi;
+            }
+        }
+        __syncthreads();
+        const float* xrow = s_x + j * QS + 4 * h;
+        float part = tower_mlp_part<L3>(s_img, lane, [&](int q) {
+            return *reinterpret_cast<const f32x4*>(xrow + 8 * q);
+        });
+        if constexpr (G > 0) {
+            const float* grow = s_gp + j * GS + h * (G / 2);
+            const float* wpg = s_img + IMG_WPG + h * (G / 2);
+#pragma unroll
+            for (int c = 0; c < G / 8; ++c) {
+                const f32x4 gp = *reinterpret_cast<const f32x4*>(grow + 4 * c);
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wpg + 4 * c);
+                part = fmaf(gp.x, w.x, part);
+                part = fmaf(gp.y, w.y, part);
+                part = fmaf(gp.z, w.z, part);
+                part = fmaf(gp.w, w.w, part);
+            }
+        }
+        const float total = part + __shfl_xor(part, 32) + a.bp;
+        const int64_t b = base + j;
+        if (h == 0 && b < a.B) a.out[b] = epilogue(total, a.act, a.lo, a.hi);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GMF-only model (model_name == 'GMF', ncf_model.py:232-234): score = w . (eu * ei) + b
+// ---------------------------------------------------------------------------------------------
+struct GmfArgs {
+    const float* EUg;
+    const float* EIg;
+    const float* wp;
+    const int64_t* user;
+    const int64_t* item;
+    int64_t n_users, n_items, B;
+    int G;
+    float* out;
+    float bp;
+    int act;
+    float lo, hi;
+    int32_t* oob;
+};
+
+// 8 lanes per pair, each lane one float4 chunk per step: rows are read as whole 128-B lines.
+__global__ __launch_bounds__(256) void gmf_pairs_kernel(GmfArgs a)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t b = t >> 3;
+    const int sub = threadIdx.x & 7;
+    float part = 0.f;
+    if (b < a.B) {
+        const int64_t u = clamp_id(a.user ? a.user[b] : b, a.n_users, sub == 0 ? a.oob : nullptr);
+        const int64_t i = clamp_id(a.item ? a.item[b] : b, a.n_items, sub == 0 ? a.oob : nullptr);
+        for (int c = sub; c < a.G / 4; c += 8) {
+            const f32x4 gu = reinterpret_cast<const f32x4*>(a.EUg + u * a.G)[c];
+            const f32x4 gi = reinterpret_cast<const f32x4*>(a.EIg + i * a.G)[c];
+            const f32x4 w = reinterpret_cast<const f32x4*>(a.wp)[c];
+            part = fmaf(gu.x * gi.x, w.x, part);
+            part = fmaf(gu.y * gi.y, w.y, part);
+            part = fmaf(gu.z * gi.z, w.z, part);
+            part = fmaf(gu.w * gi.w, w.w, part);
+        }
+    }
+    part += __shfl_xor(part, 1);
+    part += __shfl_xor(part, 2);
+    part += __shfl_xor(part, 4);
+    if (b < a.B && sub == 0) a.out[b] = epilogue(part + a.bp, a.act, a.lo, a.hi);
+}
+
+// matrix form: one thread per (user, item); user row in registers is re-read through L1.
+struct GmfTileArgs {
+    const float* EUg;
+    const float* EIg;
+    const float* wp;
+    const int64_t* users;
+    const int64_t* cands;
+    int64_t user_base, n_users, n_items, U, N;
+    int G;
+    float* out;
+    int64_t ld_out;
+    float bp;
+    int act;
+    float lo, hi;
+    int32_t* oob;
+};
+
+__global__ __launch_bounds__(256) void gmf_tile_kernel(GmfTileArgs a)
+{
+    // block = 256 items x 16 users; item rows staged once per block in registers of each thread
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t u0 = (int64_t)blockIdx.y * 16;
+    extern __shared__ __attribute__((aligned(16))) float s_u[];   // [16][G] user rows pre-multiplied? no: raw
+    for (int i = threadIdx.x; i < 16 * a.G; i += 256) {
+        const int64_t u = u0 + i / a.G;
+        float v = 0.f;
+        if (u < a.U) {
+            const int64_t uid = clamp_id(a.users ? a.users[u] : a.user_base + u, a.n_users,
+                                         (i % a.G == 0 && blockIdx.x == 0) ? a.oob : nullptr);
+            v = a.EUg[uid * a.G + i % a.G];
+        }
+        s_u[i] = v;
+    }
+    __syncthreads();
+    if (n >= a.N) return;
+    const int64_t id = clamp_id(a.cands ? a.cands[n] : n, a.n_items, blockIdx.y == 0 ? a.oob : nullptr);
+    const f32x4* gi = reinterpret_cast<const f32x4*>(a.EIg + id * a.G);
+    for (int uu = 0; uu < 16 && u0 + uu < a.U; ++uu) {
+        float part = 0.f;
+        for (int c = 0; c < a.G / 4; ++c) {
+            const f32x4 g = gi[c];
+            const f32x4 gu = *reinterpret_cast<const f32x4*>(s_u + uu * a.G + 4 * c);
+            const f32x4 w = reinterpret_cast<const f32x4*>(a.wp)[c];
+            part = fmaf(gu.x * g.x, w.x, part);
+            part = fmaf(gu.y * g.y, w.y, part);
+            part = fmaf(gu.z * g.z, w.z, part);
+            part = fmaf(gu.w * g.w, w.w, part);
+        }
+        a.out[(u0 + uu) * a.ld_out + n] = epilogue(part + a.bp, a.act, a.lo, a.hi);
+    }
+}
+
+template <int G, bool L3>
+int launch_tile_t(const TileArgs& a, hipStream_t s)
+{
+    constexpr size_t lds = (size_t)(IMG_SIZE + TI * QS + (G > 0 ? TI * (G + 4) : 0)) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        RECO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_tile_kernel<G, L3>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int64_t blocks = ceil_div64(a.N, TI) * ceil_div64(a.U, TUB);
+    RECO_REQUIRE(blocks < (1ll << 31), "tower tile grid too large (%lld blocks)", (long long)blocks);
+    hipLaunchKernelGGL((tower_tile_kernel<G, L3>), dim3((unsigned)blocks), dim3(512), lds, s, a);
+    RECO_CHECK_LAUNCH();
+    return RECO_OK;
+}
+
+template <int G, bool L3>
+int launch_pairs_t(const PairArgs& a, hipStream_t s)
+{
+    constexpr size_t lds = (size_t)(IMG_SIZE + 4 * (32 * QS + (G > 0 ? 32 * (G + 4) : 0))) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        RECO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_pairs_kernel<G, L3>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int64_t nchunks = ceil_div64(a.B, 128);
+    const unsigned grid = (unsigned)(nchunks < 1024 ? nchunks : 1024);
+    hipLaunchKernelGGL((tower_pairs_kernel<G, L3>), dim3(grid), dim3(256), lds, s, a);
+    RECO_CHECK_LAUNCH();
+    return RECO_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// host-side entry points used by api.hip
+// ---------------------------------------------------------------------------------------------
+int tower_pack_image(const float* W2, const float* b2, const float* W3, const float* b3, const float* wp,
+                     int G, int has_l3, float* img, hipStream_t s)
+{
+    PackArgs p{W2, b2, W3, b3, wp, G, has_l3};
+    hipLaunchKernelGGL(pack_image_kernel, dim3((IMG_SIZE + 255) / 256), dim3(256), 0, s, p, img);
+    RECO_CHECK_LAUNCH();
+    return RECO_OK;
+}
+
+int tower_launch_tile(int G, int has_l3, const float* img, const float* P, const float* Q,
+                      const float* EUg, const float* EIg, const int64_t* users, const int64_t* cands,
+                      int64_t user_base, int64_t n_users, int64_t n_items, int64_t U, int64_t N,
+                      float* out, int64_t ld_out, float bp, int act, float lo, float hi, int32_t* oob,
+                      hipStream_t s)
+{
+    if (U <= 0 || N <= 0) return RECO_OK;
+    TileArgs a{img, P, Q, EUg, EIg, users, cands, user_base, n_users, n_items, U, N, out, ld_out, bp, act, lo, hi, oob};
+    if (G == 32 && has_l3) return launch_tile_t<32, true>(a, s);
+    if (G == 0 && has_l3) return launch_tile_t<0, true>(a, s);
+    if (G == 64 && !has_l3) return launch_tile_t<64, false>(a, s);
+    reco_set_error("tower tile kernel: unsupported configuration G=%d has_l3=%d", G, has_l3);
+    return RECO_EINVAL;
+}
+
+int tower_launch_pairs(int G, int has_l3, const float* img, const float* P, const float* Q,
+                       const float* EUg, const float* EIg, const int64_t* user, const int64_t* item,
+                       int64_t n_users, int64_t n_items, int64_t B, float* out, float bp, int act,
+                       float lo, float hi, int32_t* oob, hipStream_t s)
+{
+    if (B <= 0) return RECO_OK;
+    PairArgs a{img, P, Q, EUg, EIg, user, item, n_users, n_items, B, out, bp, act, lo, hi, oob};
+    if (G == 32 && has_l3) return launch_pairs_t<32, true>(a, s);
+    if (G == 0 && has_l3) return launch_pairs_t<0, true>(a, s);
+    if (G == 64 && !has_l3) return launch_pairs_t<64, false>(a, s);
+    reco_set_error("tower pair kernel: unsupported configuration G=%d has_l3=%d", G, has_l3);
+    return RECO_EINVAL;
+}
+
+int gmf_launch_pairs(const float* EUg, const float* EIg, const float* wp, const int64_t* user,
+                     const int64_t* item, int64_t n_users, int64_t n_items, int64_t B, int G, float* out,
+                     float bp, int act, float lo, float hi, int32_t* oob, hipStream_t s)
+{
+    if (B <= 0) return RECO_OK;
+    GmfArgs a{EUg, EIg, wp, user, item, n_users, n_items, B, G, out, bp, act, lo, hi, oob};
+    const int64_t blocks = ceil_div64(B * 8, 256);
+    RECO_REQUIRE(blocks < (1ll << 31), "gmf pair grid too large");
+    hipLaunchKernelGGL(gmf_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    RECO_CHECK_LAUNCH();
+    return RECO_OK;
+}
+
+int gmf_launch_tile(const float* EUg, const float* EIg, const float* wp, const int64_t* users,
+                    const int64_t* cands, int64_t user_base, int64_t n_users, int64_t n_items, int64_t U,
+                    int64_t N, int G, float* out, int64_t ld_out, float bp, int act, float lo, float hi,
+                    int32_t* oob, hipStream_t s)
+{
+    if (U <= 0 || N <= 0) return RECO_OK;
+    GmfTileArgs a{EUg, EIg, wp, users, cands, user_base, n_users, n_items, U, N, G, out, ld_out, bp, act, lo, hi, oob};
+    const int64_t by = ceil_div64(U, 16);
+    RECO_REQUIRE(by <= 65535, "gmf tile: too many users per call (%lld); chunk the call", (long long)U);
+    hipLaunchKernelGGL(gmf_tile_kernel, dim3((unsigned)ceil_div64(N, 256), (unsigned)by), dim3(256),
+                       (size_t)16 * G * sizeof(float), s, a);
+    RECO_CHECK_LAUNCH();
+    return RECO_OK;
+}

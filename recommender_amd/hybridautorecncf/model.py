@@ -1,0 +1,167 @@
+"""Hybrid AutoRec -> NCF model on the MI355X kernels.
+
+Mirrors the classes of src/hybridautorecncf/evaluate_hybridautorecncf_rating.py:58-208 (rating variant:
+raw decoder, sigmoid-scaled prediction) and of hybridautorecncf.ipynb cells 1-3 (logit variant: Sigmoid
+decoder, logit prediction).  The two share every state_dict key (user_autorec.encoder.{0,3,6}, ...
+ncf.mlp.{0,3}, ncf.output), so the variant is chosen by constructor flags, not by the checkpoint.
+
+forward(user_vecs, item_vecs, user_ids, item_ids) -> (pred[B], user_recon, item_recon) keeps the
+reference semantics (encoders, decoders and head for every pair of the batch).  `score_all` is the
+full-catalog path (cfg4): encode every user and item ONCE, then the fused head over all pairs --
+instead of the reference's O(blocks x items) full-model loop (hybridautorecncf.ipynb cell 13).
+"""
+import weakref
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+_tower_cache = weakref.WeakKeyDictionary()
+
+
+def _f32_on(t, device):
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class AutoEncoder(nn.Module):
+    def __init__(self, input_dim: int, latent_dim: int, hidden_dims=(256, 128), dropout_rate: float = 0.1,
+                 sigmoid_output: bool = False):
+        super().__init__()
+        self.sigmoid_output = sigmoid_output
+        enc, width = [], input_dim
+        for h in hidden_dims:                                   # Linear, ReLU, Dropout triples -> keys encoder.{0,3}
+            enc += [nn.Linear(width, h), nn.ReLU(), nn.Dropout(dropout_rate)]
+            width = h
+        enc.append(nn.Linear(width, latent_dim))                # bottleneck, no activation -> key encoder.6
+        self.encoder = nn.Sequential(*enc)
+        dec, width = [], latent_dim
+        for h in reversed(hidden_dims):
+            dec += [nn.Linear(width, h), nn.ReLU(), nn.Dropout(dropout_rate)]
+            width = h
+        dec.append(nn.Linear(width, input_dim))
+        if sigmoid_output:
+            dec.append(nn.Sigmoid())                            # notebook (implicit) variant
+        self.decoder = nn.Sequential(*dec)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                nn.init.zeros_(m.bias)
+
+    @staticmethod
+    def _run(seq, x, final_act):
+        linears = [m for m in seq if isinstance(m, nn.Linear)]
+        for n, lin in enumerate(linears):
+            last = n + 1 == len(linears)
+            x = ops.linear(x, _f32_on(lin.weight, x.device), _f32_on(lin.bias, x.device),
+                           act=(final_act if last else "relu"))
+        return x
+
+    def _prep(self, x):
+        ops.require_gpu()
+        if any(isinstance(m, nn.Dropout) and m.p > 0 for m in self.modules()) and self.training:
+            raise RuntimeError("recommender_amd AutoEncoder is inference-only: call .eval() first")
+        device = x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        return x.to(device=device, dtype=torch.float32)
+
+    def encode(self, x):
+        src = x.device
+        z = self._run(self.encoder, self._prep(x), None)
+        return z if z.device == src else z.to(src)
+
+    def decode(self, z):
+        src = z.device
+        r = self._run(self.decoder, self._prep(z), "sigmoid" if self.sigmoid_output else None)
+        return r if r.device == src else r.to(src)
+
+    def forward(self, x):
+        z = self.encode(x)
+        return self.decode(z), z
+
+
+class NCF(nn.Module):
+    """The hybrid's scoring head: GMF product + MLP over the two latents, one output unit."""
+
+    def __init__(self, latent_dim, mlp_layers=(128, 64), dropout_rate=0.1, rating_min=1.0, rating_max=5.0,
+                 rating_output: bool = True):
+        super().__init__()
+        self.rating_min = rating_min
+        self.rating_max = rating_max
+        self.rating_output = rating_output
+        stack, width = [], 2 * latent_dim
+        for h in mlp_layers:                                    # keys mlp.{0,3}
+            stack += [nn.Linear(width, h), nn.ReLU(), nn.Dropout(dropout_rate)]
+            width = h
+        self.mlp = nn.Sequential(*stack)
+        self.output = nn.Linear(latent_dim + (mlp_layers[-1] if len(mlp_layers) else 2 * latent_dim), 1)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    def _tower(self, device):
+        linears = [m for m in self.mlp if isinstance(m, nn.Linear)]
+        ps = [p for lin in linears for p in (lin.weight, lin.bias)] + [self.output.weight, self.output.bias]
+        sig = (str(device), bool(self.rating_output), float(self.rating_min), float(self.rating_max)) + tuple(
+            (p.data_ptr(), p._version, str(p.device)) for p in ps)
+        hit = _tower_cache.get(self)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        latent = self.output.in_features - linears[-1].out_features
+        tower = ops.Tower(layers=[(_f32_on(l.weight, device), _f32_on(l.bias, device)) for l in linears],
+                          w_predict=_f32_on(self.output.weight, device), b_predict=_f32_on(self.output.bias, device),
+                          dg=latent, dm=latent, act="rating" if self.rating_output else None,
+                          lo=float(self.rating_min), hi=float(self.rating_max))
+        _tower_cache[self] = (sig, tower)
+        return tower
+
+    def forward(self, user_z, item_z):
+        ops.require_gpu()
+        src = user_z.device
+        device = src if user_z.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        zu = _f32_on(user_z, device); zi = _f32_on(item_z, device)
+        if zu.shape != zi.shape:
+            raise ValueError("user_z and item_z must have the same shape")
+        out = self._tower(device).score_rows(zu, zi, zu, zi)
+        return out if out.device == src else out.to(src)
+
+    def score_matrix(self, zu, zi):
+        """pred[u, i] for every (row of zu, row of zi): the full-catalog form of forward."""
+        ops.require_gpu()
+        device = zu.device if zu.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        zu = _f32_on(zu, device); zi = _f32_on(zi, device)
+        linears = [m for m in self.mlp if isinstance(m, nn.Linear)]
+        tower = ops.Tower(user_gmf=zu, item_gmf=zi, user_mlp=zu, item_mlp=zi,
+                          layers=[(_f32_on(l.weight, device), _f32_on(l.bias, device)) for l in linears],
+                          w_predict=_f32_on(self.output.weight, device), b_predict=_f32_on(self.output.bias, device),
+                          act="rating" if self.rating_output else None, lo=float(self.rating_min), hi=float(self.rating_max))
+        return tower
+
+
+class HybridAutoRecNCF(nn.Module):
+    def __init__(self, num_users, num_items, latent_dim, mlp_layers, hidden_dims=(256, 128), dropout_rate=0.1,
+                 rating_output: bool = True):
+        """rating_output=True: the `-Rating` variant (raw decoders, sigmoid*4+1 prediction);
+        rating_output=False: HybridAutoRecNCF.pth / `-Ranking` (Sigmoid decoders, logit prediction)."""
+        super().__init__()
+        self.user_autorec = AutoEncoder(num_items, latent_dim, hidden_dims, dropout_rate, sigmoid_output=not rating_output)
+        self.item_autorec = AutoEncoder(num_users, latent_dim, hidden_dims, dropout_rate, sigmoid_output=not rating_output)
+        self.ncf = NCF(latent_dim, mlp_layers, dropout_rate, rating_output=rating_output)
+
+    def forward(self, user_vecs, item_vecs, user_ids=None, item_ids=None):
+        user_recon, user_z = self.user_autorec(user_vecs)
+        item_recon, item_z = self.item_autorec(item_vecs)
+        return self.ncf(user_z, item_z), user_recon, item_recon
+
+    def score_all(self, rating_matrix, k=None, exclude=None):
+        """Full-catalog joint scoring (cfg4): pred[users, items], or per-user top-k when k is given."""
+        ops.require_gpu()
+        device = rating_matrix.device if rating_matrix.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        R = rating_matrix.to(device=device, dtype=torch.float32).contiguous()
+        zu = self.user_autorec.encode(R)
+        zi = self.item_autorec.encode(R.t().contiguous())
+        tower = self.ncf.score_matrix(zu, zi)
+        if k is None:
+            return tower.score_matrix(None, None, check_ids=False)
+        return tower.score_topk(None, k, None, exclude, check_ids=False)

@@ -1,0 +1,308 @@
+"""Tensor-level wrappers over the C ABI: check tensors, pull data_ptr()/current stream, call libreco_hip.
+
+Everything here runs on the GPU through libreco_hip.so; there is no eager-PyTorch arithmetic on the
+product path.  torch is used for allocation (torch.empty), streams and device guards only.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_CLAMP, ACT_NONE, ACT_RATING, ACT_RELU, ACT_SIGMOID, TowerDesc, check  # noqa: F401
+
+ACTS = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "sigmoid": ACT_SIGMOID, "clamp": ACT_CLAMP, "rating": ACT_RATING}
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("recommender_amd needs an AMD GPU (gfx950 / MI355X): there is no CPU fallback")
+
+
+def _f32(t, name, dim=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise ValueError("%s must live on the GPU" % name)
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32, got %s" % (name, t.dtype))
+    if dim is not None and t.dim() != dim:
+        raise ValueError("%s must be %d-D, got shape %s" % (name, dim, tuple(t.shape)))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _i64(t, name, device):
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(t, dtype=torch.int64)
+    if t.dtype != torch.int64:
+        if t.dtype in (torch.int32, torch.int16, torch.int8, torch.uint8):
+            t = t.to(torch.int64)
+        else:
+            raise TypeError("%s must be an integer tensor, got %s" % (name, t.dtype))
+    if t.dim() != 1:
+        raise ValueError("%s must be 1-D, got shape %s" % (name, tuple(t.shape)))
+    t = t.to(device, non_blocking=True)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+# ----------------------------------------------------------------------------------------------
+# K-a gathers
+# ----------------------------------------------------------------------------------------------
+def gather_rows(table, idx, check_ids=True):
+    """out[b] = table[idx[b]]  (nn.Embedding forward, ncf_model.py:207-208)."""
+    table = _f32(table, "table", 2)
+    idx = _i64(idx, "idx", table.device)
+    out = torch.empty((idx.numel(), table.shape[1]), dtype=torch.float32, device=table.device)
+    oob = torch.zeros(1, dtype=torch.int32, device=table.device) if check_ids else None
+    with torch.cuda.device(table.device):
+        check(_lib.lib().reco_gather_rows(_p(table), table.shape[0], table.shape[1], _p(idx), idx.numel(), _p(out),
+                                          _p(oob), _stream(table.device)))
+    if check_ids and int(oob.item()):
+        raise IndexError("index out of range in self")
+    return out
+
+
+def neumf_gather(eu_g, ei_g, eu_m, ei_m, user, item, check_ids=True):
+    """(gmf_prod [B,dg], mlp_in [B,2*dm]) as the reference materialises them (ncf_model.py:207-224)."""
+    dev = (eu_g if eu_g is not None else eu_m).device
+    user = _i64(user, "user", dev); item = _i64(item, "item", dev)
+    if user.numel() != item.numel():
+        raise ValueError("user and item must have the same length")
+    B = user.numel()
+    gp = mi = None
+    n_users = n_items = dg = dm = 0
+    if eu_g is not None:
+        eu_g = _f32(eu_g, "embed_user_GMF", 2); ei_g = _f32(ei_g, "embed_item_GMF", 2)
+        n_users, dg = eu_g.shape; n_items = ei_g.shape[0]
+        gp = torch.empty((B, dg), dtype=torch.float32, device=dev)
+    if eu_m is not None:
+        eu_m = _f32(eu_m, "embed_user_MLP", 2); ei_m = _f32(ei_m, "embed_item_MLP", 2)
+        n_users, dm = eu_m.shape; n_items = ei_m.shape[0]
+        mi = torch.empty((B, 2 * dm), dtype=torch.float32, device=dev)
+    oob = torch.zeros(1, dtype=torch.int32, device=dev) if check_ids else None
+    with torch.cuda.device(dev):
+        check(_lib.lib().reco_neumf_gather(_p(eu_g), _p(ei_g), _p(eu_m), _p(ei_m), n_users, n_items, dg, dm,
+                                           _p(user), _p(item), B, _p(gp), _p(mi), _p(oob), _stream(dev)))
+    if check_ids and int(oob.item()):
+        raise IndexError("index out of range in self")
+    return gp, mi
+
+
+# ----------------------------------------------------------------------------------------------
+# K-c Linear / AutoRec
+# ----------------------------------------------------------------------------------------------
+def linear(x, weight, bias=None, act=None, lo=0.0, hi=0.0, out=None):
+    """act(x @ weight.T + bias) on the fp32 MFMA GEMM (nn.Linear + fused activation)."""
+    x = _f32(x, "input", 2); weight = _f32(weight, "weight", 2)
+    if bias is not None:
+        bias = _f32(bias, "bias", 1)
+    M, K = x.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K:
+        raise ValueError("mat1 and mat2 shapes cannot be multiplied (%dx%d and %dx%d)" % (M, K, weight.shape[1], N))
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().reco_linear_f32(_p(x), K, None, 0, M, _p(weight), K, _p(bias), N, K, ACTS[act], lo, hi,
+                                         _p(out), N, _stream(x.device)))
+    return out
+
+
+def autorec_forward(x, we, be, wd, bd, clamp=None):
+    """decoder(sigmoid(encoder(x))) (+clamp) -- src/autorec/utils/model.py:31-33, inference_engine.py:232."""
+    x = _f32(x, "input", 2)
+    we = _f32(we, "encoder.0.weight", 2); be = _f32(be, "encoder.0.bias", 1)
+    wd = _f32(wd, "decoder.0.weight", 2); bd = _f32(bd, "decoder.0.bias", 1)
+    B, n_in = x.shape
+    hidden = we.shape[0]
+    if we.shape[1] != n_in or wd.shape != (n_in, hidden):
+        raise ValueError("AutoRec shape mismatch: input %s encoder %s decoder %s" % (tuple(x.shape), tuple(we.shape), tuple(wd.shape)))
+    h = torch.empty((B, hidden), dtype=torch.float32, device=x.device)
+    out = torch.empty((B, n_in), dtype=torch.float32, device=x.device)
+    act, lo, hi = (ACT_NONE, 0.0, 0.0) if clamp is None else (ACT_CLAMP, float(clamp[0]), float(clamp[1]))
+    with torch.cuda.device(x.device):
+        check(_lib.lib().reco_autorec_forward(_p(x), B, _p(we), _p(be), _p(wd), _p(bd), n_in, hidden, act, lo, hi,
+                                              _p(h), _p(out), _stream(x.device)))
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# K-d top-k
+# ----------------------------------------------------------------------------------------------
+def topk_rows(scores, k, exclude=None):
+    """(ids int32 [rows,k], vals [rows,k]): descending score, ascending position among equals.
+
+    exclude (bool/uint8 [rows,N]) applies helper.py:313 (score*(~seen) - seen*1e10) before the select.
+    """
+    scores = _f32(scores, "scores", 2)
+    rows, N = scores.shape
+    if exclude is not None:
+        exclude = _mask(exclude, scores)
+    ids = torch.empty((rows, k), dtype=torch.int32, device=scores.device)
+    vals = torch.empty((rows, k), dtype=torch.float32, device=scores.device)
+    L = _lib.lib()
+    nbytes = L.reco_topk_workspace_bytes(rows, N, k)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=scores.device)
+    with torch.cuda.device(scores.device):
+        check(L.reco_topk_rows(_p(scores), rows, N, N, k, _p(exclude), N, _p(ids), _p(vals), _p(ws), nbytes,
+                               _stream(scores.device)))
+    return ids, vals
+
+
+def _mask(m, like):
+    if not isinstance(m, torch.Tensor):
+        m = torch.as_tensor(m)
+    if m.dtype == torch.bool:
+        m = m.to(torch.uint8)
+    if m.dtype != torch.uint8:
+        raise TypeError("exclude mask must be bool or uint8")
+    m = m.to(like.device)
+    if m.dim() != 2:
+        raise ValueError("exclude mask must be 2-D")
+    return m if m.is_contiguous() else m.contiguous()
+
+
+# ----------------------------------------------------------------------------------------------
+# K-b tower handle
+# ----------------------------------------------------------------------------------------------
+class Tower:
+    """Owns a reco_tower_t.  Keeps the weight tensors alive (the handle borrows their memory)."""
+
+    def __init__(self, *, user_gmf=None, item_gmf=None, user_mlp=None, item_mlp=None, layers=(), w_predict, b_predict,
+                 dg=None, dm=None, act=None, lo=1.0, hi=5.0):
+        require_gpu()
+        dev = w_predict.device
+        self.device = dev
+        keep = []
+
+        def f(t, name, dim):
+            if t is None:
+                return None
+            t = _f32(t, name, dim)
+            keep.append(t)
+            return t
+
+        user_gmf = f(user_gmf, "user_gmf", 2); item_gmf = f(item_gmf, "item_gmf", 2)
+        user_mlp = f(user_mlp, "user_mlp", 2); item_mlp = f(item_mlp, "item_mlp", 2)
+        d = TowerDesc()
+        d.user_gmf = user_gmf.data_ptr() if user_gmf is not None else None
+        d.item_gmf = item_gmf.data_ptr() if item_gmf is not None else None
+        d.user_mlp = user_mlp.data_ptr() if user_mlp is not None else None
+        d.item_mlp = item_mlp.data_ptr() if item_mlp is not None else None
+        tab_u = user_gmf if user_gmf is not None else user_mlp
+        tab_i = item_gmf if item_gmf is not None else item_mlp
+        d.n_users = tab_u.shape[0] if tab_u is not None else 0
+        d.n_items = tab_i.shape[0] if tab_i is not None else 0
+        d.dg = int(dg if dg is not None else (user_gmf.shape[1] if user_gmf is not None else 0))
+        d.dm = int(dm if dm is not None else (user_mlp.shape[1] if user_mlp is not None else 0))
+        if len(layers) > 3:
+            raise ValueError("reco_hip: at most 3 MLP layers are supported, got %d" % len(layers))
+        d.n_layers = len(layers)
+        for i, (w, b) in enumerate(layers):
+            w = f(w, "W[%d]" % i, 2); b = f(b, "b[%d]" % i, 1)
+            d.W[i] = w.data_ptr(); d.b[i] = b.data_ptr(); d.layer_out[i] = w.shape[0]
+        wp = f(w_predict.reshape(-1), "w_predict", 1); bp = f(b_predict.reshape(-1), "b_predict", 1)
+        d.w_predict = wp.data_ptr(); d.b_predict = bp.data_ptr()
+        d.act = ACTS[act]; d.lo = lo; d.hi = hi
+        self.n_users, self.n_items = int(d.n_users), int(d.n_items)
+        self._keep = keep
+        self._h = ctypes.c_void_p()
+        self._L = _lib.lib()
+        with torch.cuda.device(dev):
+            check(self._L.reco_tower_create(ctypes.byref(d), _stream(dev), ctypes.byref(self._h)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self._L.reco_tower_destroy(h)
+            self._h = None
+
+    def _raise_if_oob(self):
+        n = self._L.reco_tower_status(self._h, _stream(self.device))
+        if n < 0:
+            raise RuntimeError("reco_hip: reco_tower_status failed")
+        if n:
+            raise IndexError("index out of range in self")
+
+    def score_pairs(self, user, item, check_ids=True):
+        user = _i64(user, "user", self.device); item = _i64(item, "item", self.device)
+        if user.numel() != item.numel():
+            raise ValueError("user and item must have the same length (%d vs %d)" % (user.numel(), item.numel()))
+        out = torch.empty(user.numel(), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self._L.reco_tower_score_pairs(self._h, _p(user), _p(item), user.numel(), _p(out), _stream(self.device)))
+            if check_ids:
+                self._raise_if_oob()
+        return out
+
+    def score_rows(self, u_gmf, i_gmf, u_mlp, i_mlp):
+        ref = u_mlp if u_mlp is not None else u_gmf
+        B = ref.shape[0]
+        tens = [None if t is None else _f32(t, "rows", 2) for t in (u_gmf, i_gmf, u_mlp, i_mlp)]
+        out = torch.empty(B, dtype=torch.float32, device=self.device)
+        nbytes = self._L.reco_tower_rows_workspace_bytes(B)
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self._L.reco_tower_score_rows(self._h, _p(tens[0]), _p(tens[1]), _p(tens[2]), _p(tens[3]), B, _p(out),
+                                                _p(ws), nbytes, _stream(self.device)))
+        return out
+
+    def _users(self, users):
+        """users: None (all), int range tuple (base, count), or id tensor."""
+        if users is None:
+            return None, 0, self.n_users
+        if isinstance(users, tuple):
+            return None, int(users[0]), int(users[1])
+        users = _i64(users, "users", self.device)
+        return users, 0, users.numel()
+
+    def score_matrix(self, users=None, cands=None, check_ids=True, out=None):
+        uptr, base, U = self._users(users)
+        if cands is not None:
+            cands = _i64(cands, "candidates", self.device)
+        N = cands.numel() if cands is not None else self.n_items
+        if out is None:
+            out = torch.empty((U, N), dtype=torch.float32, device=self.device)
+        nbytes = self._L.reco_tower_matrix_workspace_bytes(U, N)
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self._L.reco_tower_score_matrix(self._h, _p(uptr), base, U, _p(cands), N, _p(out), out.stride(0),
+                                                  _p(ws), nbytes, _stream(self.device)))
+            if check_ids:
+                self._raise_if_oob()
+        return out
+
+    def topk_workspace(self, U, N, k):
+        nbytes = self._L.reco_tower_topk_workspace_bytes(U, N, k)
+        return torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.device)
+
+    def score_topk(self, users=None, k=10, cands=None, exclude=None, check_ids=True, ws=None, out=None):
+        """(ids int32 [U,k] = positions in `cands` (item ids when cands is None), scores [U,k])."""
+        uptr, base, U = self._users(users)
+        if cands is not None:
+            cands = _i64(cands, "candidates", self.device)
+        N = cands.numel() if cands is not None else self.n_items
+        if exclude is not None:
+            exclude = _mask(exclude, self._keep[0])
+            if tuple(exclude.shape) != (U, N):
+                raise ValueError("exclude mask must have shape (%d, %d), got %s" % (U, N, tuple(exclude.shape)))
+        if out is None:
+            ids = torch.empty((U, k), dtype=torch.int32, device=self.device)
+            vals = torch.empty((U, k), dtype=torch.float32, device=self.device)
+        else:
+            ids, vals = out
+        if ws is None:
+            ws = self.topk_workspace(U, N, k)
+        with torch.cuda.device(self.device):
+            check(self._L.reco_tower_score_topk(self._h, _p(uptr), base, U, _p(cands), N, k, _p(exclude), N, _p(ids),
+                                                _p(vals), _p(ws), ws.numel(), _stream(self.device)))
+            if check_ids:
+                self._raise_if_oob()
+        return ids, vals
