@@ -171,6 +171,17 @@ int reco_topk_rows(const float* scores, int64_t rows, int64_t N, int64_t ld, int
                    const uint8_t* exclude, int64_t ld_ex,
                    int32_t* out_ids, float* out_vals, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Measurement hook (no counterpart in the reference): when enabled, the library brackets every
+ * launch of the dominant kernel (the tower tile kernel of score_matrix / score_topk, or the pair
+ * kernel of score_pairs / score_rows) with a hipEvent pair recorded on the launch stream.
+ * reco_profile_enable(n) allocates n event pairs (n = 0 disables and frees them);
+ * reco_profile_collect synchronises the recorded events and returns per-launch milliseconds
+ * (host pointers), then rearms.  Used by bench.py for roofline.achieved.
+ * ---------------------------------------------------------------------------------------- */
+int reco_profile_enable(int max_launches);
+int reco_profile_collect(float* ms_out /*host*/, int capacity, int* n_out /*host*/);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,8 @@ _SIGNATURES = {
     "reco_topk_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "reco_topk_rows": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p,
                                c_void_p, c_size_t, c_void_p]),
+    "reco_profile_enable": (c_int, [c_int]),
+    "reco_profile_collect": (c_int, [POINTER(c_float), c_int, POINTER(c_int)]),
 }
 
 EXPORTS = tuple(sorted(_SIGNATURES))

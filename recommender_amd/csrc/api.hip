@@ -45,6 +45,55 @@ extern "C" const char* reco_last_error(void) { return g_err; }
 extern "C" int reco_abi_version(void) { return 1; }
 
 // ---------------------------------------------------------------------------------------------
+// measurement hook: hipEvent pairs around the dominant kernel's launches
+// ---------------------------------------------------------------------------------------------
+#include <vector>
+static std::vector<hipEvent_t> g_prof_ev;   // 2 per launch
+static int g_prof_used = 0;
+
+extern "C" int reco_profile_enable(int max_launches)
+{
+    for (hipEvent_t e : g_prof_ev) (void)hipEventDestroy(e);
+    g_prof_ev.clear();
+    g_prof_used = 0;
+    for (int i = 0; i < 2 * max_launches; ++i) {
+        hipEvent_t e;
+        RECO_CHECK_HIP(hipEventCreate(&e));
+        g_prof_ev.push_back(e);
+    }
+    return RECO_OK;
+}
+
+extern "C" int reco_profile_collect(float* ms_out, int capacity, int* n_out)
+{
+    RECO_REQUIRE(ms_out && n_out, "profile_collect: null pointer");
+    int n = 0;
+    for (int i = 0; i < g_prof_used && n < capacity; ++i, ++n) {
+        RECO_CHECK_HIP(hipEventSynchronize(g_prof_ev[2 * i + 1]));
+        RECO_CHECK_HIP(hipEventElapsedTime(&ms_out[n], g_prof_ev[2 * i], g_prof_ev[2 * i + 1]));
+    }
+    *n_out = n;
+    g_prof_used = 0;
+    return RECO_OK;
+}
+
+struct ProfScope {
+    hipStream_t s;
+    int slot;
+    explicit ProfScope(hipStream_t st) : s(st), slot(-1)
+    {
+        if ((size_t)(2 * g_prof_used + 1) < g_prof_ev.size()) {
+            slot = g_prof_used++;
+            (void)hipEventRecord(g_prof_ev[2 * slot], s);
+        }
+    }
+    ~ProfScope()
+    {
+        if (slot >= 0) (void)hipEventRecord(g_prof_ev[2 * slot + 1], s);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
 // Linear / AutoRec
 // ---------------------------------------------------------------------------------------------
 extern "C" int reco_linear_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_t a_row_limit, int64_t M,
@@ -217,6 +266,7 @@ extern "C" int reco_tower_score_pairs(reco_tower_t* t, const int64_t* user, cons
     if (!t->mfma)
         return gmf_launch_pairs(d.user_gmf, d.item_gmf, d.w_predict, user, item, d.n_users, d.n_items, B, d.dg, out,
                                 t->bp, d.act, d.lo, d.hi, t->oob, s);
+    ProfScope prof(s);
     return tower_launch_pairs(t->G, t->has_l3, t->img, t->P, t->Q, d.user_gmf, d.item_gmf, user, item, d.n_users,
                               d.n_items, B, out, t->bp, d.act, d.lo, d.hi, t->oob, s);
 }
@@ -246,6 +296,7 @@ extern "C" int reco_tower_score_rows(reco_tower_t* t, const float* u_gmf, const 
     float* Q = reinterpret_cast<float*>(static_cast<char*>(ws) + half);
     int rc = tower_project(t, u_mlp, nullptr, 0, B, i_mlp, nullptr, 0, B, P, Q, s);
     if (rc) return rc;
+    ProfScope prof(s);
     return tower_launch_pairs(t->G, t->has_l3, t->img, P, Q, u_gmf, i_gmf, nullptr, nullptr, B, B, B, out, t->bp,
                               d.act, d.lo, d.hi, nullptr, s);
 }
@@ -267,6 +318,7 @@ static int score_matrix_impl(reco_tower* t, const int64_t* users, int64_t user_b
     const float* urows = users ? d.user_mlp : d.user_mlp + user_base * d.dm;
     int rc = tower_project(t, urows, users, d.n_users, U, d.item_mlp, cands, d.n_items, Qready ? 0 : N, P, Q, s);
     if (rc) return rc;
+    ProfScope prof(s);
     return tower_launch_tile(t->G, t->has_l3, t->img, P, Qready ? Qready : Q, d.user_gmf, d.item_gmf, users, cands,
                              user_base, d.n_users, d.n_items, U, N, out, ld_out, t->bp, d.act, d.lo, d.hi, t->oob, s);
 }
