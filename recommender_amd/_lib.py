@@ -9,7 +9,8 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libreco_hip.so")
+# RECO_HIP_LIB selects another build of the same library (diagnostic / ablation builds); never a different backend
+LIB_PATH = os.environ.get("RECO_HIP_LIB") or os.path.join(_HERE, "lib", "libreco_hip.so")
 
 OK, EINVAL, EHIP, ENOMEM, EINDEX = 0, -1, -2, -3, -4
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_CLAMP, ACT_RATING = 0, 1, 2, 3, 4

@@ -81,10 +81,19 @@ __global__ void pack_image_kernel(PackArgs a, float* __restrict__ img)
 // ---------------------------------------------------------------------------------------------
 // the per-group MFMA body, shared by the tile and the pair kernel
 // ---------------------------------------------------------------------------------------------
+// ReLU as ONE VALU instruction.  fmaxf() on an MFMA result makes hipcc emit a canonicalising v_max in
+// front of the real one (2 instructions), and beside f32 MFMAs every VALU instruction costs MFMA issue
+// time.  max on the raw bits is exact: negative floats (and -0.0) are negative integers -> +0.0,
+// non-negative floats are unchanged.  (A positive NaN stays NaN, a negative NaN becomes 0.)
+__device__ __forceinline__ float relu1(float v)
+{
+    return __int_as_float(max(__float_as_int(v), 0));
+}
+
 __device__ __forceinline__ f32x4 relu4(f32x4 v)
 {
     f32x4 r;
-    r.x = fmaxf(v.x, 0.f); r.y = fmaxf(v.y, 0.f); r.z = fmaxf(v.z, 0.f); r.w = fmaxf(v.w, 0.f);
+    r.x = relu1(v.x); r.y = relu1(v.y); r.z = relu1(v.z); r.w = relu1(v.w);
     return r;
 }
 
@@ -105,16 +114,17 @@ __device__ __forceinline__ float dot16_relu(const f32x16 acc, const float* s_w, 
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
         const f32x4 w = *reinterpret_cast<const f32x4*>(s_w + (rq * 2 + h) * 4);
-        part = fmaf(w.x, fmaxf(acc[4 * rq + 0], 0.f), part);
-        part = fmaf(w.y, fmaxf(acc[4 * rq + 1], 0.f), part);
-        part = fmaf(w.z, fmaxf(acc[4 * rq + 2], 0.f), part);
-        part = fmaf(w.w, fmaxf(acc[4 * rq + 3], 0.f), part);
+        part = fmaf(w.x, relu1(acc[4 * rq + 0]), part);
+        part = fmaf(w.y, relu1(acc[4 * rq + 1]), part);
+        part = fmaf(w.z, relu1(acc[4 * rq + 2]), part);
+        part = fmaf(w.w, relu1(acc[4 * rq + 3]), part);
     }
     return part;
 }
 
 // Layers 2 (+3) and the MLP half of the predict layer for the 32 pairs of this wave.
-// x1(q) must return this lane's 4 layer-1 activations relu(P+Q)[8q + 4h .. 8q + 4h + 3] for its pair.
+// x1.raw(q) issues the LDS read of this lane's 4 layer-1 inputs [8q + 4h .. 8q + 4h + 3] for its pair and
+// x1.finish(q, raw) turns them into activations relu(P + Q) (identity when the staged tile already holds them).
 template <bool L3, typename X1>
 __device__ __forceinline__ float tower_mlp_part(const float* s_img, int lane, X1 x1)
 {
@@ -122,39 +132,68 @@ __device__ __forceinline__ float tower_mlp_part(const float* s_img, int lane, X1
     f32x16 acc0 = bias16(s_img + IMG_B2, h);
     f32x16 acc1 = bias16(s_img + IMG_B2 + 32, h);
     const f32x4* w2 = reinterpret_cast<const f32x4*>(s_img + IMG_W2) + lane;
+    // software-pipelined by one quad: the LDS reads (and the add+ReLU) of quad q+1 are issued ahead of
+    // the 8 MFMAs of quad q, so no MFMA waits on an LDS round trip
+    f32x4 x = x1.finish(0, x1.raw(0));
+    f32x4 a0 = w2[0];
+    f32x4 a1 = w2[16 * 64];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        const f32x4 x = x1(q);
-        const f32x4 a0 = w2[q * 64];
-        const f32x4 a1 = w2[(16 + q) * 64];
+        f32x4 xraw = x, a0n = a0, a1n = a1;
+        if (q + 1 < 16) {                       // issue quad q+1's three ds_read_b128 first ...
+            xraw = x1.raw(q + 1);
+#ifndef RECO_ABL_NO_W2_READS
+            a0n = w2[(q + 1) * 64];
+            a1n = w2[(16 + q + 1) * 64];
+#endif
+        }
+        __builtin_amdgcn_sched_barrier(0);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, x.x, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, x.x, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, x.y, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, x.y, acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 xn = x;
+#ifdef RECO_ABL_NO_X1_VALU
+        if (q + 1 < 16) xn = xraw;
+#else
+        if (q + 1 < 16) xn = x1.finish(q + 1, xraw);   // ... their data is back 4 MFMAs (256 cycles) later
+#endif
+        __builtin_amdgcn_sched_barrier(0);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, x.z, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, x.z, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, x.w, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, x.w, acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        x = xn; a0 = a0n; a1 = a1n;
     }
     float part = 0.f;
+#ifdef RECO_ABL_NO_L3
+    return acc0[0] + acc1[0];
+#endif
     if constexpr (L3) {
         f32x16 acc3 = bias16(s_img + IMG_B3, h);
         const f32x4* w3 = reinterpret_cast<const f32x4*>(s_img + IMG_W3) + lane;
+        f32x4 a = w3[0];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const f32x4 a = w3[q * 64];
+            f32x4 an = a;
+            if (q + 1 < 8) an = w3[(q + 1) * 64];   // one quad ahead, as in layer 2
+            __builtin_amdgcn_sched_barrier(0);
             const int r = 4 * (q & 3);
             if (q < 4) {
-                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, fmaxf(acc0[r + 0], 0.f), acc3, 0, 0, 0);
-                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, fmaxf(acc0[r + 1], 0.f), acc3, 0, 0, 0);
-                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, fmaxf(acc0[r + 2], 0.f), acc3, 0, 0, 0);
-                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, fmaxf(acc0[r + 3], 0.f), acc3, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, relu1(acc0[r + 0]), acc3, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, relu1(acc0[r + 1]), acc3, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, relu1(acc0[r + 2]), acc3, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, relu1(acc0[r + 3]), acc3, 0, 0, 0);
             } else {
-                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, fmaxf(acc1[r + 0], 0.f), acc3, 0, 0, 0);
-                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, fmaxf(acc1[r + 1], 0.f), acc3, 0, 0, 0);
-                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, fmaxf(acc1[r + 2], 0.f), acc3, 0, 0, 0);
-                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, fmaxf(acc1[r + 3], 0.f), acc3, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, relu1(acc1[r + 0]), acc3, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, relu1(acc1[r + 1]), acc3, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, relu1(acc1[r + 2]), acc3, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, relu1(acc1[r + 3]), acc3, 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            a = an;
         }
         part = dot16_relu(acc3, s_img + IMG_WPM, h, part);
     } else {
@@ -180,11 +219,21 @@ __device__ __forceinline__ int64_t clamp_id(int64_t id, int64_t n, int32_t* oob)
 }
 
 // ---------------------------------------------------------------------------------------------
-// tile kernel: scores for (user chunk) x (item tile)
+// tile kernel: scores for (user chunk) x (item tile); persistent, one 8-wave workgroup per CU
 // ---------------------------------------------------------------------------------------------
-constexpr int TI = 128;        // items per tile (4 MFMA column groups)
-constexpr int TUB = 32;        // users per block (4 per wave)
+// Each workgroup loads the weight image once and then walks tiles blockIdx.x, blockIdx.x + grid, ...
+// A tile is TUB users x TI items.  The item side of a tile (Q rows, GMF item rows) lives in one of
+// two LDS buffers: while the 8 waves run the MFMAs of tile i out of buffer i & 1, the global loads of
+// tile i + 1 are in flight into registers, are written to the other buffer after the last MFMA and
+// published by the single __syncthreads() per tile.  Wave w owns users w, w + 8, ... of the tile:
+// their P rows (64 VGPRs) stay in registers across the tile's item groups.
+constexpr int TI = 64;         // items per tile (2 MFMA column groups)
+#ifndef RECO_TUB
+#define RECO_TUB 32
+#endif
+constexpr int TUB = RECO_TUB;   // users per tile (4 per wave)
 constexpr int QS = H1 + 4;     // padded LDS row stride of the Q tile: conflict-free ds_read_b128 by 16 rows
+constexpr int TILE_THREADS = 512;
 
 struct TileArgs {
     const float* img;
@@ -204,14 +253,65 @@ struct TileArgs {
     int32_t* oob;
 };
 
+template <int G>
+struct TileStage {
+    static constexpr int NQ = TI * (H1 / 4) / TILE_THREADS;                 // float4 of Q per thread (4)
+    static constexpr int NG = G > 0 ? (TI * (G / 4) + TILE_THREADS - 1) / TILE_THREADS : 0;
+    f32x4 q[NQ];
+    f32x4 g[NG > 0 ? NG : 1];
+};
+
+template <int G>
+__device__ __forceinline__ void tile_stage_load(const TileArgs& a, int64_t n0, bool count_oob, int tid, TileStage<G>& st)
+{
+#pragma unroll
+    for (int s = 0; s < TileStage<G>::NQ; ++s) {
+        const int i = tid + s * TILE_THREADS;
+        const int64_t n = n0 + (i >> 5);
+        st.q[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (n < a.N) st.q[s] = reinterpret_cast<const f32x4*>(a.Q + n * H1)[i & 31];
+    }
+    if constexpr (G > 0) {
+#pragma unroll
+        for (int s = 0; s < TileStage<G>::NG; ++s) {
+            const int i = tid + s * TILE_THREADS;
+            const int r = i / (G / 4), c = i % (G / 4);
+            const int64_t n = n0 + r;
+            st.g[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r < TI && n < a.N) {
+                const int64_t id = clamp_id(a.cands ? a.cands[n] : n, a.n_items, (c == 0 && count_oob) ? a.oob : nullptr);
+                st.g[s] = reinterpret_cast<const f32x4*>(a.EIg + id * G)[c];
+            }
+        }
+    }
+}
+
+template <int G>
+__device__ __forceinline__ void tile_stage_store(float* s_q, float* s_g, int tid, const TileStage<G>& st)
+{
+#pragma unroll
+    for (int s = 0; s < TileStage<G>::NQ; ++s) {
+        const int i = tid + s * TILE_THREADS;
+        *reinterpret_cast<f32x4*>(s_q + (i >> 5) * QS + (i & 31) * 4) = st.q[s];
+    }
+    if constexpr (G > 0) {
+#pragma unroll
+        for (int s = 0; s < TileStage<G>::NG; ++s) {
+            const int i = tid + s * TILE_THREADS;
+            const int r = i / (G / 4), c = i % (G / 4);
+            if (r < TI) *reinterpret_cast<f32x4*>(s_g + r * (G + 4) + c * 4) = st.g[s];
+        }
+    }
+}
+
 template <int G, bool L3>
-__global__ __launch_bounds__(512, 2) void tower_tile_kernel(TileArgs a)
+__global__ __launch_bounds__(TILE_THREADS, 2) void tower_tile_kernel(TileArgs a)
 {
     constexpr int GS = G + 4;
+    constexpr int BUF = TI * QS + (G > 0 ? TI * GS : 0);      // floats per item-side buffer
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_img = smem;
-    float* s_q = smem + IMG_SIZE;
-    float* s_g = s_q + TI * QS;
+    float* s_buf = smem + IMG_SIZE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -219,74 +319,87 @@ __global__ __launch_bounds__(512, 2) void tower_tile_kernel(TileArgs a)
     const int j = lane & 31, h = lane >> 5;
 
     const int64_t tiles_n = (a.N + TI - 1) / TI;
-    const int64_t n0 = (int64_t)(blockIdx.x % tiles_n) * TI;
-    const int64_t u0 = (int64_t)(blockIdx.x / tiles_n) * TUB;
+    const int64_t tiles = tiles_n * ((a.U + TUB - 1) / TUB);
 
-    for (int i = tid; i < IMG_SIZE / 4; i += 512)
+    for (int i = tid; i < IMG_SIZE / 4; i += TILE_THREADS)
         reinterpret_cast<f32x4*>(s_img)[i] = reinterpret_cast<const f32x4*>(a.img)[i];
-    for (int i = tid; i < TI * (H1 / 4); i += 512) {
-        const int r = i >> 5, c = i & 31;
-        const int64_t n = n0 + r;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (n < a.N) v = reinterpret_cast<const f32x4*>(a.Q + n * H1)[c];
-        *reinterpret_cast<f32x4*>(s_q + r * QS + c * 4) = v;
-    }
-    if constexpr (G > 0) {
-        for (int i = tid; i < TI * (G / 4); i += 512) {
-            const int r = i / (G / 4), c = i % (G / 4);
-            const int64_t n = n0 + r;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n < a.N) {
-                const int64_t id = clamp_id(a.cands ? a.cands[n] : n, a.n_items, c == 0 && blockIdx.x < tiles_n ? a.oob : nullptr);
-                v = reinterpret_cast<const f32x4*>(a.EIg + id * G)[c];
-            }
-            *reinterpret_cast<f32x4*>(s_g + r * GS + c * 4) = v;
-        }
+
+#ifdef RECO_DIAG_CLOCK
+    const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    TileStage<G> st;
+    int64_t tile = blockIdx.x;
+    if (tile < tiles) {
+        tile_stage_load<G>(a, (tile % tiles_n) * TI, tile / tiles_n == 0, tid, st);
+        tile_stage_store<G>(s_buf, s_buf + TI * QS, tid, st);
     }
     __syncthreads();
 
-    for (int uu = wave; uu < TUB; uu += 8) {
-        const int64_t u = u0 + uu;
-        if (u >= a.U) break;
-        f32x4 p[16];
-        const f32x4* prow = reinterpret_cast<const f32x4*>(a.P + u * H1 + 4 * h);
+    for (int it = 0; tile < tiles; tile += gridDim.x, ++it) {
+        const float* s_q = s_buf + (it & 1) * BUF;
+        const float* s_g = s_q + TI * QS;
+        const int64_t n0 = (tile % tiles_n) * TI;
+        const int64_t u0 = (tile / tiles_n) * TUB;
+        const int64_t next = tile + gridDim.x;
+        if (next < tiles) tile_stage_load<G>(a, (next % tiles_n) * TI, next / tiles_n == 0, tid, st);
+
+        for (int uu = wave; uu < TUB; uu += TILE_THREADS / 64) {
+            const int64_t u = u0 + uu;
+            if (u >= a.U) break;
+            f32x4 p[16];
+            const f32x4* prow = reinterpret_cast<const f32x4*>(a.P + u * H1 + 4 * h);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) p[q] = prow[2 * q];
-        f32x4 gu[G > 0 ? G / 8 : 1];
-        if constexpr (G > 0) {
-            const int64_t uid = clamp_id(a.users ? a.users[u] : a.user_base + u, a.n_users,
-                                         (lane == 0 && n0 == 0) ? a.oob : nullptr);
-            const f32x4* gr = reinterpret_cast<const f32x4*>(a.EUg + uid * G + h * (G / 2));
-#pragma unroll
-            for (int c = 0; c < G / 8; ++c) gu[c] = gr[c];
-        }
-#pragma unroll 1
-        for (int g = 0; g < TI / 32; ++g) {
-            // keep the (loop-invariant) weight-image reads inside the loop: hoisted, they would pin ~200 VGPRs
-            asm volatile("" ::: "memory");
-            const float* qrow = s_q + (g * 32 + j) * QS + 4 * h;
-            float part = tower_mlp_part<L3>(s_img, lane, [&](int q) {
-                const f32x4 qv = *reinterpret_cast<const f32x4*>(qrow + 8 * q);
-                return relu4(p[q] + qv);
-            });
+            for (int q = 0; q < 16; ++q) p[q] = prow[2 * q];
+            f32x4 gu[G > 0 ? G / 8 : 1];
             if constexpr (G > 0) {
-                const float* grow = s_g + (g * 32 + j) * GS + h * (G / 2);
+                const int64_t uid = clamp_id(a.users ? a.users[u] : a.user_base + u, a.n_users,
+                                             (lane == 0 && n0 == 0) ? a.oob : nullptr);
+                const f32x4* gr = reinterpret_cast<const f32x4*>(a.EUg + uid * G + h * (G / 2));
                 const float* wpg = s_img + IMG_WPG + h * (G / 2);
 #pragma unroll
-                for (int c = 0; c < G / 8; ++c) {
-                    const f32x4 gi = *reinterpret_cast<const f32x4*>(grow + 4 * c);
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(wpg + 4 * c);
-                    part = fmaf(gu[c].x * gi.x, w.x, part);
-                    part = fmaf(gu[c].y * gi.y, w.y, part);
-                    part = fmaf(gu[c].z * gi.z, w.z, part);
-                    part = fmaf(gu[c].w * gi.w, w.w, part);
-                }
+                for (int c = 0; c < G / 8; ++c)   // fold the predict weights into the user row once per user
+                    gu[c] = gr[c] * *reinterpret_cast<const f32x4*>(wpg + 4 * c);
             }
-            const float total = part + __shfl_xor(part, 32) + a.bp;
-            const int64_t n = n0 + g * 32 + j;
-            if (h == 0 && n < a.N) a.out[u * a.ld_out + n] = epilogue(total, a.act, a.lo, a.hi);
+#pragma unroll 1
+            for (int g = 0; g < TI / 32; ++g) {
+                // keep the (loop-invariant) weight-image reads inside the loop: hoisted, they would pin ~200 VGPRs
+                asm volatile("" ::: "memory");
+                const float* qrow = s_q + (g * 32 + j) * QS + 4 * h;
+                struct X1Tile {
+                    const float* qrow;
+                    const f32x4* p;
+                    __device__ __forceinline__ f32x4 raw(int q) const { return *reinterpret_cast<const f32x4*>(qrow + 8 * q); }
+                    __device__ __forceinline__ f32x4 finish(int q, f32x4 v) const { return relu4(p[q] + v); }
+                };
+                float part = tower_mlp_part<L3>(s_img, lane, X1Tile{qrow, p});
+                if constexpr (G > 0) {
+                    const float* grow = s_g + (g * 32 + j) * GS + h * (G / 2);
+#pragma unroll
+                    for (int c = 0; c < G / 8; ++c) {
+                        const f32x4 gi = *reinterpret_cast<const f32x4*>(grow + 4 * c);
+                        part = fmaf(gu[c].x, gi.x, part);
+                        part = fmaf(gu[c].y, gi.y, part);
+                        part = fmaf(gu[c].z, gi.z, part);
+                        part = fmaf(gu[c].w, gi.w, part);
+                    }
+                }
+                const float total = part + __shfl_xor(part, 32) + a.bp;
+                const int64_t n = n0 + g * 32 + j;
+                if (h == 0 && n < a.N) a.out[u * a.ld_out + n] = epilogue(total, a.act, a.lo, a.hi);
+            }
         }
+        if (next < tiles) {
+            float* d_q = s_buf + ((it + 1) & 1) * BUF;
+            tile_stage_store<G>(d_q, d_q + TI * QS, tid, st);
+        }
+        __syncthreads();   // tile i fully consumed, tile i + 1 fully staged
     }
+#ifdef RECO_DIAG_CLOCK
+    if (tid == 0 && (blockIdx.x & 63) == 0) {
+        const unsigned long long c = __builtin_amdgcn_s_memtime() - diag_c0, r = __builtin_amdgcn_s_memrealtime() - diag_r0;
+        printf("block %u: %llu cycles, %llu x10ns -> %.0f MHz\n", blockIdx.x, c, r, (double)c / (double)r * 100.0);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -364,9 +477,12 @@ __global__ __launch_bounds__(256, 1) void tower_pairs_kernel(PairArgs a)
         }
         __syncthreads();
         const float* xrow = s_x + j * QS + 4 * h;
-        float part = tower_mlp_part<L3>(s_img, lane, [&](int q) {
-            return *reinterpret_cast<const f32x4*>(xrow + 8 * q);
-        });
+        struct X1Pair {
+            const float* xrow;
+            __device__ __forceinline__ f32x4 raw(int q) const { return *reinterpret_cast<const f32x4*>(xrow + 8 * q); }
+            __device__ __forceinline__ f32x4 finish(int, f32x4 v) const { return v; }
+        };
+        float part = tower_mlp_part<L3>(s_img, lane, X1Pair{xrow});
         if constexpr (G > 0) {
             const float* grow = s_gp + j * GS + h * (G / 2);
             const float* wpg = s_img + IMG_WPG + h * (G / 2);
@@ -485,16 +601,20 @@ __global__ __launch_bounds__(256) void gmf_tile_kernel(GmfTileArgs a)
 template <int G, bool L3>
 int launch_tile_t(const TileArgs& a, hipStream_t s)
 {
-    constexpr size_t lds = (size_t)(IMG_SIZE + TI * QS + (G > 0 ? TI * (G + 4) : 0)) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    constexpr size_t lds = (size_t)(IMG_SIZE + 2 * (TI * QS + (G > 0 ? TI * (G + 4) : 0))) * sizeof(float);
+    static_assert(lds <= 160 * 1024, "tile kernel LDS budget");
+    static int n_cu = 0;
+    if (n_cu == 0) {
         RECO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_tile_kernel<G, L3>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        int dev = 0;
+        RECO_CHECK_HIP(hipGetDevice(&dev));
+        RECO_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        if (n_cu <= 0) n_cu = 256;
     }
-    const int64_t blocks = ceil_div64(a.N, TI) * ceil_div64(a.U, TUB);
-    RECO_REQUIRE(blocks < (1ll << 31), "tower tile grid too large (%lld blocks)", (long long)blocks);
-    hipLaunchKernelGGL((tower_tile_kernel<G, L3>), dim3((unsigned)blocks), dim3(512), lds, s, a);
+    const int64_t tiles = ceil_div64(a.N, TI) * ceil_div64(a.U, TUB);
+    const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);   // one resident 8-wave workgroup per CU
+    hipLaunchKernelGGL((tower_tile_kernel<G, L3>), dim3(grid), dim3(TILE_THREADS), lds, s, a);
     RECO_CHECK_LAUNCH();
     return RECO_OK;
 }
