@@ -67,6 +67,18 @@ def cpu_baseline(model, check_ids, check_vals, budget_s=12.0):
                           done, N_ITEMS, chunk, K, el, torch.__version__, threads, K, ok, same_ids)}
 
 
+def measured_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, guide's gfx950 correction)."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if f.endswith("_hbm_traffic.json"):
+            for name, v in json.load(open(os.path.join(pdir, f)))["kernels"].items():
+                if kernel_substr in name and "hbm_bytes_per_launch_corrected" in v:
+                    best = v["hbm_bytes_per_launch_corrected"]
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,7 +155,10 @@ def main():
                        "users_per_gpu": N_USERS, "items": N_ITEMS, "k": K, "weights": "random init, reference ctor order, seed 0, embeddings x25",
                        "parallelism": "user-sharded x%d, replicated tables, RCCL all-gather of top-k" % world},
             "roofline": {"bound": "mfma", "kernel": "tower_tile_kernel<32,true>", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": measured_traffic("tower_tile_kernel<32, true>") if world == 1 else None,
+                         "traffic_note": "HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/*_hbm_traffic.json), not live; "
+                                         "algorithmic output is 85.3 MB per launch",
                          "kernel_ms": tile_ms, "launches_timed": n.value, "flop_per_pair_algorithmic": FLOP_PER_PAIR,
                          "executed": {"flop_per_pair": FLOP_PER_PAIR_EXEC, "achieved": executed, "frac": executed / PEAK_F32_MFMA_TFLOPS,
                                       "note": "layer 1 is factorised (W1[u;i] = W1u u + W1i i): frac above counts the reference's "
