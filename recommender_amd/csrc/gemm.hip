@@ -44,27 +44,41 @@ __device__ __forceinline__ float apply_act(float v, int act, float lo, float hi)
     }
 }
 
-template <bool VEC4>
+// 4 consecutive k of one row.  VEC = 4 / 2 / 1: widest load the row alignment allows (K = 3706 rows are only 8-B aligned).
+template <int VEC, bool GUARD>
 __device__ __forceinline__ f32x4 load_k4(const float* row, int64_t k, int64_t K)
 {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (row == nullptr) return v;
-    if (VEC4 && k + 3 < K) return *reinterpret_cast<const f32x4*>(row + k);
-    if (k + 0 < K) v.x = row[k + 0];
-    if (k + 1 < K) v.y = row[k + 1];
-    if (k + 2 < K) v.z = row[k + 2];
-    if (k + 3 < K) v.w = row[k + 3];
+    if (!GUARD || k + 3 < K) {
+        if constexpr (VEC == 4) {
+            v = *reinterpret_cast<const f32x4*>(row + k);
+        } else if constexpr (VEC == 2) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 lo = *reinterpret_cast<const f32x2*>(row + k), hi = *reinterpret_cast<const f32x2*>(row + k + 2);
+            v = f32x4{lo.x, lo.y, hi.x, hi.y};
+        } else {
+            v = f32x4{row[k], row[k + 1], row[k + 2], row[k + 3]};
+        }
+    } else {
+        if (k + 0 < K) v.x = row[k + 0];
+        if (k + 1 < K) v.y = row[k + 1];
+        if (k + 2 < K) v.z = row[k + 2];
+    }
     return v;
 }
 
-// block = 256 threads = 4 waves as 2 (M) x 2 (N); wave tile = (BM/2) x (BN/2) = TM x TN MFMA tiles of 32x32
-template <int BM, int BN, bool VEC4>
+// block = 256 threads = 4 waves as 2 (M) x 2 (N); wave tile = (BM/2) x (BN/2) = TM x TN MFMA tiles of 32x32.
+// K is consumed in BK = 32 tiles through a double-buffered LDS image: the global loads of tile t+1 are issued before
+// the MFMAs of tile t and written to the other buffer after them -- one barrier per tile, no branch in the steady state
+// (rows past M / N are clamped to the last row and discarded at the store; only the ragged last K tile is guarded).
+template <int BM, int BN, int VEC>
 __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
 {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int RA = BM / 32, RB = BN / 32;   // float4 per thread per operand per K tile
-    __shared__ __attribute__((aligned(16))) float s_a[BM * LS];
-    __shared__ __attribute__((aligned(16))) float s_b[BN * LS];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // layout: [buf][A tile BM*LS | B tile BN*LS]
+    constexpr int BUF = (BM + BN) * LS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -82,24 +96,23 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
     const float* wrow[RB];
 #pragma unroll
     for (int s = 0; s < RA; ++s) {
-        const int64_t m = m0 + sr + 32 * s;
-        arow[s] = nullptr;
-        if (m < a.M) {
-            int64_t r = m;
-            if (a.a_rows) {
-                r = a.a_rows[m];
-                if (r < 0 || r >= a.a_row_limit) {
-                    if (a.oob && sc == 0 && n0 == 0) atomicAdd(a.oob, 1);
-                    r = r < 0 ? 0 : a.a_row_limit - 1;
-                }
+        int64_t m = m0 + sr + 32 * s;
+        if (m >= a.M) m = a.M - 1;
+        int64_t r = m;
+        if (a.a_rows) {
+            r = a.a_rows[m];
+            if (r < 0 || r >= a.a_row_limit) {
+                if (a.oob && sc == 0 && n0 == 0 && m0 + sr + 32 * s < a.M) atomicAdd(a.oob, 1);
+                r = r < 0 ? 0 : a.a_row_limit - 1;
             }
-            arow[s] = a.A + r * a.lda;
         }
+        arow[s] = a.A + r * a.lda + 4 * sc;
     }
 #pragma unroll
     for (int s = 0; s < RB; ++s) {
-        const int64_t n = n0 + sr + 32 * s;
-        wrow[s] = n < a.N ? a.W + n * a.ldw : nullptr;
+        int64_t n = n0 + sr + 32 * s;
+        if (n >= a.N) n = a.N - 1;
+        wrow[s] = a.W + n * a.ldw + 4 * sc;
     }
 
     f32x16 acc[TM][TN];
@@ -110,34 +123,48 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
+    const int64_t nt = (a.K + BK - 1) / BK;
+    const bool ragged = (a.K % BK) != 0;
     f32x4 ra[RA], rb[RB];
-#pragma unroll
-    for (int s = 0; s < RA; ++s) ra[s] = load_k4<VEC4>(arow[s], 4 * sc, a.K);
-#pragma unroll
-    for (int s = 0; s < RB; ++s) rb[s] = load_k4<VEC4>(wrow[s], 4 * sc, a.K);
 
-    for (int64_t k0 = 0; k0 < a.K; k0 += BK) {
-        __syncthreads();   // everyone is done reading the previous tile
+    auto load_tile = [&](int64_t t) {
+        const int64_t k0 = t * BK;
+        if (ragged && t == nt - 1) {
+#pragma unroll
+            for (int s = 0; s < RA; ++s) ra[s] = load_k4<1, true>(arow[s], k0, a.K - 4 * sc);
+#pragma unroll
+            for (int s = 0; s < RB; ++s) rb[s] = load_k4<1, true>(wrow[s], k0, a.K - 4 * sc);
+        } else {
+#pragma unroll
+            for (int s = 0; s < RA; ++s) ra[s] = load_k4<VEC, false>(arow[s], k0, a.K);
+#pragma unroll
+            for (int s = 0; s < RB; ++s) rb[s] = load_k4<VEC, false>(wrow[s], k0, a.K);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* s_a = smem + buf * BUF;
+        float* s_b = s_a + BM * LS;
 #pragma unroll
         for (int s = 0; s < RA; ++s) *reinterpret_cast<f32x4*>(s_a + (sr + 32 * s) * LS + 4 * sc) = ra[s];
 #pragma unroll
         for (int s = 0; s < RB; ++s) *reinterpret_cast<f32x4*>(s_b + (sr + 32 * s) * LS + 4 * sc) = rb[s];
-        __syncthreads();
-        if (k0 + BK < a.K) {   // prefetch the next tile into registers while this one is consumed
-#pragma unroll
-            for (int s = 0; s < RA; ++s) ra[s] = load_k4<VEC4>(arow[s], k0 + BK + 4 * sc, a.K);
-#pragma unroll
-            for (int s = 0; s < RB; ++s) rb[s] = load_k4<VEC4>(wrow[s], k0 + BK + 4 * sc, a.K);
-        }
+    };
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int64_t t = 0; t < nt; ++t) {
+        if (t + 1 < nt) load_tile(t + 1);
+        const float* s_a = smem + (t & 1) * BUF + (wm * (BM / 2) + i) * LS + 4 * h;
+        const float* s_b = smem + (t & 1) * BUF + BM * LS + (wn * (BN / 2) + i) * LS + 4 * h;
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {
             f32x4 fa[TM], fb[TN];
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-                fa[tm] = *reinterpret_cast<const f32x4*>(s_a + (wm * (BM / 2) + tm * 32 + i) * LS + 8 * q + 4 * h);
+            for (int tm = 0; tm < TM; ++tm) fa[tm] = *reinterpret_cast<const f32x4*>(s_a + tm * 32 * LS + 8 * q);
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-                fb[tn] = *reinterpret_cast<const f32x4*>(s_b + (wn * (BN / 2) + tn * 32 + i) * LS + 8 * q + 4 * h);
+            for (int tn = 0; tn < TN; ++tn) fb[tn] = *reinterpret_cast<const f32x4*>(s_b + tn * 32 * LS + 8 * q);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
@@ -146,6 +173,8 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
                     for (int tn = 0; tn < TN; ++tn)
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm][jj], fb[tn][jj], acc[tm][tn], 0, 0, 0);
         }
+        if (t + 1 < nt) store_tile((t + 1) & 1);
+        __syncthreads();
     }
 
     // epilogue: D[row = (r&3) + 8 (r>>2) + 4 h][col = lane & 31]
@@ -165,17 +194,38 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
     }
 }
 
-template <int BM, int BN>
-int launch_t(const LinArgs& a, bool vec4, hipStream_t s)
+template <int BM, int BN, int VEC>
+int launch_v(const LinArgs& a, hipStream_t s)
 {
+    constexpr size_t lds = (size_t)2 * (BM + BN) * LS * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        RECO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel<BM, BN, VEC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
     const int64_t blocks = ceil_div64(a.M, BM) * ceil_div64(a.N, BN);
     RECO_REQUIRE(blocks < (1ll << 31), "linear grid too large");
-    if (vec4)
-        hipLaunchKernelGGL((linear_kernel<BM, BN, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((linear_kernel<BM, BN, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((linear_kernel<BM, BN, VEC>), dim3((unsigned)blocks), dim3(256), lds, s, a);
     RECO_CHECK_LAUNCH();
     return RECO_OK;
+}
+
+template <int BM, int BN>
+int launch_t(const LinArgs& a, int vec, hipStream_t s)
+{
+    if (vec == 4) return launch_v<BM, BN, 4>(a, s);
+    if (vec == 2) return launch_v<BM, BN, 2>(a, s);
+    return launch_v<BM, BN, 1>(a, s);
+}
+
+// rough utilisation model: larger tiles amortise LDS traffic better, but the grid must cover the 256 CUs
+double tile_score(int64_t M, int64_t N, int bm, int bn, double tile_eff)
+{
+    const double blocks = (double)(ceil_div64(M, bm) * ceil_div64(N, bn));
+    const double rounds = (double)ceil_div64((int64_t)blocks, 256);
+    const double useful = ((double)M * (double)N) / (blocks * bm * bn);     // padding waste of ragged edges
+    return tile_eff * useful * blocks / (rounds * 256.0);
 }
 
 }  // namespace
@@ -189,9 +239,13 @@ int launch_linear_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_
     RECO_REQUIRE(A && W && C, "linear: null pointer");
     RECO_REQUIRE(lda >= K && ldw >= K && ldc >= N, "linear: leading dimension smaller than the row");
     LinArgs a{A, lda, a_rows, a_rows ? a_row_limit : M, M, W, ldw, bias, N, K, act, lo, hi, C, ldc, oob};
-    const bool vec4 = (lda % 4 == 0) && (ldw % 4 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0);
-    // fill the 256 CUs: fall back to 64x64 tiles when 128x128 would leave most of the chip idle
-    const int64_t big = ceil_div64(M, 128) * ceil_div64(N, 128);
-    if (big >= 200) return launch_t<128, 128>(a, vec4, s);
-    return launch_t<64, 64>(a, vec4, s);
+    int vec = 1;
+    if (lda % 4 == 0 && ldw % 4 == 0 && (uintptr_t)A % 16 == 0 && (uintptr_t)W % 16 == 0) vec = 4;
+    else if (lda % 2 == 0 && ldw % 2 == 0 && (uintptr_t)A % 8 == 0 && (uintptr_t)W % 8 == 0) vec = 2;
+    const double s11 = tile_score(M, N, 128, 128, 1.00), s12 = tile_score(M, N, 128, 64, 0.85);
+    const double s21 = tile_score(M, N, 64, 128, 0.85), s22 = tile_score(M, N, 64, 64, 0.70);
+    if (s11 >= s12 && s11 >= s21 && s11 >= s22) return launch_t<128, 128>(a, vec, s);
+    if (s12 >= s21 && s12 >= s22) return launch_t<128, 64>(a, vec, s);
+    if (s21 >= s22) return launch_t<64, 128>(a, vec, s);
+    return launch_t<64, 64>(a, vec, s);
 }

@@ -421,6 +421,66 @@ struct PairArgs {
     int32_t* oob;
 };
 
+// Per wave: 32 pairs at a time, fully wave-private (no workgroup barrier in the loop).  The P/Q/GMF rows of the NEXT 32
+// pairs are in flight into registers (two whole 512-B rows per wave instruction) while the MFMAs of the current 32 run
+// out of the wave's LDS staging tile; LDS operations of one wave execute in issue order, so staging writes and operand
+// reads need no barrier between them.
+template <int G>
+struct PairStage {
+    static constexpr int NG = G > 0 ? (32 * (G / 4)) / 64 : 0;   // float4 of each GMF table per lane
+    f32x4 p[16], q[16];
+    f32x4 gu[NG > 0 ? NG : 1], gi[NG > 0 ? NG : 1];
+};
+
+template <int G>
+__device__ __forceinline__ void pair_stage_load(const PairArgs& a, int64_t base, int lane, PairStage<G>& st)
+{
+    const int j = lane & 31, h = lane >> 5;
+    int64_t my_u = 0, my_i = 0;   // ids of the 32 pairs live in lanes 0..31 (mirrored in 32..63)
+    const int64_t b = base + j;
+    if (b < a.B) {
+        my_u = clamp_id(a.user ? a.user[b] : b, a.n_users, h == 0 ? a.oob : nullptr);
+        my_i = clamp_id(a.item ? a.item[b] : b, a.n_items, h == 0 ? a.oob : nullptr);
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int pl = it * 2 + h;
+        const int64_t u = __shfl(my_u, pl);
+        const int64_t i = __shfl(my_i, pl);
+        st.p[it] = reinterpret_cast<const f32x4*>(a.P + u * H1)[j];
+        st.q[it] = reinterpret_cast<const f32x4*>(a.Q + i * H1)[j];
+    }
+    if constexpr (G > 0) {
+        constexpr int C = G / 4;
+#pragma unroll
+        for (int it = 0; it < PairStage<G>::NG; ++it) {
+            const int e = it * 64 + lane;
+            const int pl = e / C, c = e % C;
+            const int64_t u = __shfl(my_u, pl);
+            const int64_t i = __shfl(my_i, pl);
+            st.gu[it] = reinterpret_cast<const f32x4*>(a.EUg + u * G)[c];
+            st.gi[it] = reinterpret_cast<const f32x4*>(a.EIg + i * G)[c];
+        }
+    }
+}
+
+template <int G>
+__device__ __forceinline__ void pair_stage_store(float* s_x, float* s_gp, int lane, const PairStage<G>& st)
+{
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int it = 0; it < 16; ++it)
+        *reinterpret_cast<f32x4*>(s_x + (it * 2 + h) * QS + 4 * j) = relu4(st.p[it] + st.q[it]);
+    if constexpr (G > 0) {
+        constexpr int C = G / 4;
+#pragma unroll
+        for (int it = 0; it < PairStage<G>::NG; ++it) {
+            const int e = it * 64 + lane;
+            *reinterpret_cast<f32x4*>(s_gp + (e / C) * (G + 4) + 4 * (e % C)) = st.gu[it] * st.gi[it];
+        }
+    }
+}
+
 template <int G, bool L3>
 __global__ __launch_bounds__(256, 1) void tower_pairs_kernel(PairArgs a)
 {
@@ -438,44 +498,18 @@ __global__ __launch_bounds__(256, 1) void tower_pairs_kernel(PairArgs a)
 
     for (int i = tid; i < IMG_SIZE / 4; i += 256)
         reinterpret_cast<f32x4*>(s_img)[i] = reinterpret_cast<const f32x4*>(a.img)[i];
+    __syncthreads();
 
-    const int64_t nchunks = (a.B + 127) / 128;
-    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        const int64_t base = chunk * 128 + wave * 32;
-        // ids of this wave's 32 pairs live in lanes 0..31
-        int64_t my_u = 0, my_i = 0;
-        {
-            const int64_t b = base + j;
-            if (b < a.B) {
-                my_u = clamp_id(a.user ? a.user[b] : b, a.n_users, h == 0 ? a.oob : nullptr);
-                my_i = clamp_id(a.item ? a.item[b] : b, a.n_items, h == 0 ? a.oob : nullptr);
-            }
-        }
-        __syncthreads();   // previous iteration's readers are done with s_x / s_gp (and the image is loaded)
-        // stage x1 = relu(P[u] + Q[i]): one wave instruction covers two whole 512-B rows
-#pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-            const int pl = it * 2 + h;
-            const int64_t u = __shfl(my_u, pl);
-            const int64_t i = __shfl(my_i, pl);
-            const f32x4 pv = reinterpret_cast<const f32x4*>(a.P + u * H1)[j];
-            const f32x4 qv = reinterpret_cast<const f32x4*>(a.Q + i * H1)[j];
-            *reinterpret_cast<f32x4*>(s_x + pl * QS + 4 * j) = relu4(pv + qv);
-        }
-        if constexpr (G > 0) {
-            constexpr int C = G / 4;                      // float4 per row
-#pragma unroll
-            for (int it = 0; it < (32 * C) / 64; ++it) {
-                const int e = it * 64 + lane;
-                const int pl = e / C, c = e % C;
-                const int64_t u = __shfl(my_u, pl);
-                const int64_t i = __shfl(my_i, pl);
-                const f32x4 gu = reinterpret_cast<const f32x4*>(a.EUg + u * G)[c];
-                const f32x4 gi = reinterpret_cast<const f32x4*>(a.EIg + i * G)[c];
-                *reinterpret_cast<f32x4*>(s_gp + pl * GS + 4 * c) = gu * gi;
-            }
-        }
-        __syncthreads();
+    const int64_t ngroups = (a.B + 31) / 32;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t grp = (int64_t)blockIdx.x * 4 + wave;
+    PairStage<G> st;
+    if (grp < ngroups) pair_stage_load<G>(a, grp * 32, lane, st);
+    for (; grp < ngroups; grp += stride) {
+        const int64_t base = grp * 32;
+        pair_stage_store<G>(s_x, s_gp, lane, st);
+        __builtin_amdgcn_wave_barrier();
+        if (grp + stride < ngroups) pair_stage_load<G>(a, (grp + stride) * 32, lane, st);   // in flight under the MFMAs
         const float* xrow = s_x + j * QS + 4 * h;
         struct X1Pair {
             const float* xrow;
@@ -499,6 +533,7 @@ __global__ __launch_bounds__(256, 1) void tower_pairs_kernel(PairArgs a)
         const float total = part + __shfl_xor(part, 32) + a.bp;
         const int64_t b = base + j;
         if (h == 0 && b < a.B) a.out[b] = epilogue(total, a.act, a.lo, a.hi);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -630,7 +665,7 @@ int launch_pairs_t(const PairArgs& a, hipStream_t s)
         attr_set = true;
     }
     const int64_t nchunks = ceil_div64(a.B, 128);
-    const unsigned grid = (unsigned)(nchunks < 1024 ? nchunks : 1024);
+    const unsigned grid = (unsigned)(nchunks < 256 ? nchunks : 256);   // persistent: one 4-wave workgroup per CU
     hipLaunchKernelGGL((tower_pairs_kernel<G, L3>), dim3(grid), dim3(256), lds, s, a);
     RECO_CHECK_LAUNCH();
     return RECO_OK;
