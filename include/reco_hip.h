@@ -58,11 +58,14 @@ int reco_gather_rows(const float* table, int64_t rows, int dim, const int64_t* i
 /* Fused 4-table NeuMF gather: the tensors the reference materialises before its MLP,
  *   gmf_prod[b, :]  = Eu_g[user[b]] * Ei_g[item[b]]                  ncf_model.py:207-211
  *   mlp_in[b, :]    = [Eu_m[user[b]] | Ei_m[item[b]]]  (user half first) ncf_model.py:220-224
- * dg % 4 == 0, dm % 4 == 0.  Either output may be NULL to skip that half. */
+ * dg % 4 == 0, dm % 4 == 0.  Either output may be NULL to skip that half.  ld_gmf / ld_mlp are the
+ * outputs' row strides in floats (multiples of 4; 0 = dense: dg and 2*dm), so a product can be
+ * written straight into a column block of a wider buffer (the predict layer's concat, ncf_model.py:240). */
 int reco_neumf_gather(const float* Eu_g, const float* Ei_g, const float* Eu_m, const float* Ei_m,
                       int64_t n_users, int64_t n_items, int dg, int dm,
                       const int64_t* user, const int64_t* item, int64_t B,
-                      float* gmf_prod, float* mlp_in, int32_t* oob, void* stream);
+                      float* gmf_prod, int64_t ld_gmf, float* mlp_in, int64_t ld_mlp,
+                      int32_t* oob, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K-c  Linear layer as an fp32 MFMA GEMM with fused epilogue

@@ -34,7 +34,7 @@ _SIGNATURES = {
     "reco_last_error": (c_char_p, []),
     "reco_gather_rows": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "reco_neumf_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
-                                  c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                  c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     "reco_linear_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p,
                                 c_int64, c_int64, c_int, c_float, c_float, c_void_p, c_int64, c_void_p]),
     "reco_autorec_forward": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,

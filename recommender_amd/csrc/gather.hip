@@ -4,9 +4,8 @@
 //
 // A row of D floats is moved by D/4 consecutive lanes as float4, so a wave instruction touches
 // whole 128-B lines of at most 64 / (D/4) rows (D = 32: 8 rows x 128 B; D = 128: 2 rows x 512 B)
-// and the write side is fully coalesced.  Ids are read once per row group and broadcast with
-// readlane-free arithmetic (each lane loads its own row's id; the 8/32 lanes of a row hit one
-// address, which the TA coalesces).  The scoring kernels in tower.hip gather straight into LDS;
+// and the write side is fully coalesced.  Each lane loads its own row's id; the 8 / 32 lanes of a
+// row hit one address, which the texture addresser coalesces.  The scoring kernels in tower.hip gather straight into LDS;
 // these stand-alone forms exist for callers that need the materialised tensors and for the
 // HBM-roofline measurement of the gather itself.
 #include "reco_common.h"
@@ -42,6 +41,7 @@ struct FusedArgs {
     const int64_t* user; const int64_t* item;
     int64_t B;
     float* gmf_prod; float* mlp_in;
+    int64_t ldg4, ldm4;          // output row strides in float4
     int32_t* oob;
 };
 
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void neumf_gather_kernel(FusedArgs a)
                 const int64_t i = clamp_row(a.item[b], a.n_items, a.oob, c == a.m4);
                 v = reinterpret_cast<const f32x4*>(a.Ei_m)[i * a.m4 + (c - a.m4)];
             }
-            reinterpret_cast<f32x4*>(a.mlp_in)[t] = v;
+            reinterpret_cast<f32x4*>(a.mlp_in)[b * a.ldm4 + c] = v;
         }
     }
     if (a.gmf_prod) {
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void neumf_gather_kernel(FusedArgs a)
             const int c = (int)(t - b * a.g4);
             const int64_t u = clamp_row(a.user[b], a.n_users, a.oob, c == 0 && !a.mlp_in);
             const int64_t i = clamp_row(a.item[b], a.n_items, a.oob, c == 0 && !a.mlp_in);
-            reinterpret_cast<f32x4*>(a.gmf_prod)[t] =
+            reinterpret_cast<f32x4*>(a.gmf_prod)[b * a.ldg4 + c] =
                 reinterpret_cast<const f32x4*>(a.Eu_g)[u * a.g4 + c] * reinterpret_cast<const f32x4*>(a.Ei_g)[i * a.g4 + c];
         }
     }
@@ -103,14 +103,20 @@ extern "C" int reco_gather_rows(const float* table, int64_t rows, int dim, const
 extern "C" int reco_neumf_gather(const float* Eu_g, const float* Ei_g, const float* Eu_m, const float* Ei_m,
                                  int64_t n_users, int64_t n_items, int dg, int dm,
                                  const int64_t* user, const int64_t* item, int64_t B,
-                                 float* gmf_prod, float* mlp_in, int32_t* oob, void* stream)
+                                 float* gmf_prod, int64_t ld_gmf, float* mlp_in, int64_t ld_mlp,
+                                 int32_t* oob, void* stream)
 {
     if (B <= 0) return RECO_OK;
     RECO_REQUIRE(user && item, "neumf_gather: null id pointer");
     RECO_REQUIRE(!gmf_prod || (Eu_g && Ei_g && dg > 0 && dg % 4 == 0), "neumf_gather: bad GMF tables / dg=%d", dg);
     RECO_REQUIRE(!mlp_in || (Eu_m && Ei_m && dm > 0 && dm % 4 == 0), "neumf_gather: bad MLP tables / dm=%d", dm);
     RECO_REQUIRE(n_users > 0 && n_items > 0, "neumf_gather: empty tables");
-    FusedArgs a{Eu_g, Ei_g, Eu_m, Ei_m, n_users, n_items, dg / 4, dm / 4, user, item, B, gmf_prod, mlp_in, oob};
+    if (ld_gmf == 0) ld_gmf = dg;
+    if (ld_mlp == 0) ld_mlp = 2 * dm;
+    RECO_REQUIRE(ld_gmf % 4 == 0 && ld_mlp % 4 == 0 && (!gmf_prod || ld_gmf >= dg) && (!mlp_in || ld_mlp >= 2 * dm),
+                 "neumf_gather: bad output strides %lld / %lld", (long long)ld_gmf, (long long)ld_mlp);
+    RECO_REQUIRE((uintptr_t)gmf_prod % 16 == 0 && (uintptr_t)mlp_in % 16 == 0, "neumf_gather: outputs must be 16-byte aligned");
+    FusedArgs a{Eu_g, Ei_g, Eu_m, Ei_m, n_users, n_items, dg / 4, dm / 4, user, item, B, gmf_prod, mlp_in, ld_gmf / 4, ld_mlp / 4, oob};
     const int64_t work = B * (mlp_in ? 2 * (dm / 4) : dg / 4);
     hipLaunchKernelGGL(neumf_gather_kernel, dim3(stream_grid(work)), dim3(256), 0, (hipStream_t)stream, a);
     RECO_CHECK_LAUNCH();

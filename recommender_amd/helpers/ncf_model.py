@@ -118,7 +118,10 @@ class NCF(nn.Module):
             return p.detach().to(device=device, dtype=torch.float32)
 
         rating = self._rating_epilogue()
-        tower = ops.Tower(
+        layers = own.get("layers", [])
+        widths = [w.shape[0] for w, _ in layers]
+        fused = (not layers) or (widths == [128, 64, 32] and ("embed_user_GMF" not in own or own["embed_user_GMF"].shape[1] == 32))
+        tower = (ops.Tower if fused else ops.GenericTower)(
             user_gmf=dev(own["embed_user_GMF"]) if "embed_user_GMF" in own else None,
             item_gmf=dev(own["embed_item_GMF"]) if "embed_item_GMF" in own else None,
             user_mlp=dev(own["embed_user_MLP"]) if "embed_user_MLP" in own else None,

@@ -69,8 +69,11 @@ def gather_rows(table, idx, check_ids=True):
     return out
 
 
-def neumf_gather(eu_g, ei_g, eu_m, ei_m, user, item, check_ids=True):
-    """(gmf_prod [B,dg], mlp_in [B,2*dm]) as the reference materialises them (ncf_model.py:207-224)."""
+def neumf_gather(eu_g, ei_g, eu_m, ei_m, user, item, check_ids=True, gmf_out=None):
+    """(gmf_prod [B,dg], mlp_in [B,2*dm]) as the reference materialises them (ncf_model.py:207-224).
+
+    gmf_out: optional [B, >=dg] float32 view with unit inner stride (a column block of a wider buffer) to receive gmf_prod.
+    """
     dev = (eu_g if eu_g is not None else eu_m).device
     user = _i64(user, "user", dev); item = _i64(item, "item", dev)
     if user.numel() != item.numel():
@@ -81,7 +84,7 @@ def neumf_gather(eu_g, ei_g, eu_m, ei_m, user, item, check_ids=True):
     if eu_g is not None:
         eu_g = _f32(eu_g, "embed_user_GMF", 2); ei_g = _f32(ei_g, "embed_item_GMF", 2)
         n_users, dg = eu_g.shape; n_items = ei_g.shape[0]
-        gp = torch.empty((B, dg), dtype=torch.float32, device=dev)
+        gp = gmf_out if gmf_out is not None else torch.empty((B, dg), dtype=torch.float32, device=dev)
     if eu_m is not None:
         eu_m = _f32(eu_m, "embed_user_MLP", 2); ei_m = _f32(ei_m, "embed_item_MLP", 2)
         n_users, dm = eu_m.shape; n_items = ei_m.shape[0]
@@ -89,7 +92,8 @@ def neumf_gather(eu_g, ei_g, eu_m, ei_m, user, item, check_ids=True):
     oob = torch.zeros(1, dtype=torch.int32, device=dev) if check_ids else None
     with torch.cuda.device(dev):
         check(_lib.lib().reco_neumf_gather(_p(eu_g), _p(ei_g), _p(eu_m), _p(ei_m), n_users, n_items, dg, dm,
-                                           _p(user), _p(item), B, _p(gp), _p(mi), _p(oob), _stream(dev)))
+                                           _p(user), _p(item), B, _p(gp), gp.stride(0) if gp is not None and B > 0 else 0,
+                                           _p(mi), 0, _p(oob), _stream(dev)))
     if check_ids and int(oob.item()):
         raise IndexError("index out of range in self")
     return gp, mi
@@ -100,7 +104,12 @@ def neumf_gather(eu_g, ei_g, eu_m, ei_m, user, item, check_ids=True):
 # ----------------------------------------------------------------------------------------------
 def linear(x, weight, bias=None, act=None, lo=0.0, hi=0.0, out=None):
     """act(x @ weight.T + bias) on the fp32 MFMA GEMM (nn.Linear + fused activation)."""
-    x = _f32(x, "input", 2); weight = _f32(weight, "weight", 2)
+    if isinstance(x, torch.Tensor) and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1 \
+            and x.stride(0) >= x.shape[1]:
+        pass                                        # a column block of a wider row-major buffer is fine: lda = stride(0)
+    else:
+        x = _f32(x, "input", 2)
+    weight = _f32(weight, "weight", 2)
     if bias is not None:
         bias = _f32(bias, "bias", 1)
     M, K = x.shape
@@ -109,9 +118,11 @@ def linear(x, weight, bias=None, act=None, lo=0.0, hi=0.0, out=None):
         raise ValueError("mat1 and mat2 shapes cannot be multiplied (%dx%d and %dx%d)" % (M, K, weight.shape[1], N))
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    elif out.shape != (M, N) or out.dtype != torch.float32 or (N > 1 and out.stride(1) != 1):
+        raise ValueError("out must be a float32 [%d, %d] tensor with unit inner stride" % (M, N))
     with torch.cuda.device(x.device):
-        check(_lib.lib().reco_linear_f32(_p(x), K, None, 0, M, _p(weight), K, _p(bias), N, K, ACTS[act], lo, hi,
-                                         _p(out), N, _stream(x.device)))
+        check(_lib.lib().reco_linear_f32(_p(x), x.stride(0) if M > 1 else K, None, 0, M, _p(weight), K, _p(bias), N, K,
+                                         ACTS[act], lo, hi, _p(out), out.stride(0) if M > 1 else N, _stream(x.device)))
     return out
 
 
@@ -305,4 +316,93 @@ class Tower:
                                                 _p(vals), _p(ws), ws.numel(), _stream(self.device)))
             if check_ids:
                 self._raise_if_oob()
+        return ids, vals
+
+
+class GenericTower:
+    """Same interface as Tower for NCF shapes the fused MFMA kernel does not cover (factor_num != 32 or
+    num_layers != 3, e.g. the 8/16/64/128 embedding sweep of src/ncf/ncf-embedding.ipynb).
+
+    Still all-HIP, but unfused: K-a gather -> K-c Linear+ReLU per layer -> K-c predict (N = 1).  The GMF product is
+    written straight into the predict layer's concat buffer, the last MLP layer writes the other column block.
+    """
+
+    PAIRS_PER_CHUNK = 1 << 21
+
+    def __init__(self, *, user_gmf=None, item_gmf=None, user_mlp=None, item_mlp=None, layers=(), w_predict, b_predict,
+                 act=None, lo=1.0, hi=5.0):
+        require_gpu()
+        self.device = w_predict.device
+        self.ug = None if user_gmf is None else _f32(user_gmf, "user_gmf", 2)
+        self.ig = None if item_gmf is None else _f32(item_gmf, "item_gmf", 2)
+        self.um = None if user_mlp is None else _f32(user_mlp, "user_mlp", 2)
+        self.im = None if item_mlp is None else _f32(item_mlp, "item_mlp", 2)
+        self.layers = [(_f32(w, "W", 2), _f32(b, "b", 1)) for w, b in layers]
+        self.wp = _f32(w_predict.reshape(1, -1), "w_predict", 2)
+        self.bp = _f32(b_predict.reshape(-1), "b_predict", 1)
+        self.act, self.lo, self.hi = act, lo, hi
+        tab_u = self.ug if self.ug is not None else self.um
+        tab_i = self.ig if self.ig is not None else self.im
+        self.n_users, self.n_items = tab_u.shape[0], tab_i.shape[0]
+        self.dg = 0 if self.ug is None else self.ug.shape[1]
+        self.dout = self.layers[-1][0].shape[0] if self.layers else 0
+        for t in (self.ug, self.um):
+            if t is not None and t.shape[1] % 4:
+                raise ValueError("reco_hip: embedding widths must be multiples of 4, got %d" % t.shape[1])
+        if self.dg + self.dout != self.wp.shape[1]:
+            raise ValueError("predict layer width %d does not match gmf %d + mlp %d" % (self.wp.shape[1], self.dg, self.dout))
+
+    def score_pairs(self, user, item, check_ids=True):
+        user = _i64(user, "user", self.device); item = _i64(item, "item", self.device)
+        if user.numel() != item.numel():
+            raise ValueError("user and item must have the same length (%d vs %d)" % (user.numel(), item.numel()))
+        B = user.numel()
+        out = torch.empty(B, dtype=torch.float32, device=self.device)
+        for s in range(0, B, self.PAIRS_PER_CHUNK):
+            u = user[s:s + self.PAIRS_PER_CHUNK]; i = item[s:s + self.PAIRS_PER_CHUNK]
+            n = u.numel()
+            width = self.dg + self.dout
+            pad = (-width) % 4                                   # keep every row of the concat buffer 16-byte aligned
+            concat = torch.empty((n, width + pad), dtype=torch.float32, device=self.device)[:, :width]
+            gmf_view = concat[:, :self.dg] if self.dg else None
+            _, x = neumf_gather(self.ug, self.ig, self.um, self.im, u, i, check_ids, gmf_out=gmf_view)
+            for li, (w, b) in enumerate(self.layers):
+                last = li + 1 == len(self.layers)
+                x = linear(x, w, b, "relu", out=concat[:, self.dg:] if last else None)
+            linear(concat, self.wp, self.bp, self.act, self.lo, self.hi, out=out[s:s + n].view(n, 1))
+        return out
+
+    def _users(self, users):
+        if users is None:
+            return torch.arange(self.n_users, device=self.device)
+        if isinstance(users, tuple):
+            return torch.arange(users[0], users[0] + users[1], device=self.device)
+        return _i64(users, "users", self.device)
+
+    def score_matrix(self, users=None, cands=None, check_ids=True, out=None):
+        users = self._users(users)
+        cands = torch.arange(self.n_items, device=self.device) if cands is None else _i64(cands, "candidates", self.device)
+        U, N = users.numel(), cands.numel()
+        if out is None:
+            out = torch.empty((U, N), dtype=torch.float32, device=self.device)
+        step = max(1, self.PAIRS_PER_CHUNK // max(N, 1))
+        for s in range(0, U, step):
+            u = users[s:s + step]
+            out[s:s + step] = self.score_pairs(u.repeat_interleave(N), cands.repeat(u.numel()), check_ids).view(u.numel(), N)
+        return out
+
+    def topk_workspace(self, U, N, k):
+        return None
+
+    def score_topk(self, users=None, k=10, cands=None, exclude=None, check_ids=True, ws=None, out=None):
+        users = self._users(users)
+        U = users.numel()
+        N = self.n_items if cands is None else len(cands)
+        ids = torch.empty((U, k), dtype=torch.int32, device=self.device) if out is None else out[0]
+        vals = torch.empty((U, k), dtype=torch.float32, device=self.device) if out is None else out[1]
+        step = max(1, (1 << 26) // max(N, 1))
+        for s in range(0, U, step):
+            sc = self.score_matrix(users[s:s + step], cands, check_ids)
+            i, v = topk_rows(sc, k, None if exclude is None else exclude[s:s + step])
+            ids[s:s + step] = i; vals[s:s + step] = v
         return ids, vals

@@ -68,3 +68,8 @@ def g4():
 @pytest.fixture(scope="session")
 def g5():
     return load_golden("g5_metrics.npz")
+
+
+@pytest.fixture(scope="session")
+def g2b():
+    return load_golden("g2b_other_shapes.npz")

@@ -169,6 +169,29 @@ def g2_neumf_small():
 
 
 # ---------------------------------------------------------------------------
+# G2b  other tower shapes (embedding sweep of ncf-embedding.ipynb: factor 8..128; other depths)
+# ---------------------------------------------------------------------------
+def g2b_other_shapes():
+    out = {}
+    gen = torch.Generator().manual_seed(4321)
+    for tag, (factor, layers, name) in (("f16l2", (16, 2, "NeuMF-end")), ("f64l3", (64, 3, "NeuMF-end")),
+                                         ("f8l4", (8, 4, "MLP")), ("f128l1", (128, 1, "NeuMF-end")), ("f64gmf", (64, 3, "GMF"))):
+        torch.manual_seed(factor + layers)
+        U, I = 71, 53
+        m = NCF(U, I, factor, layers, 0.1, name); _liven(m, gen, 25.0 if factor <= 32 else 12.0); m.eval()
+        uu, ii = np.meshgrid(np.arange(U), np.arange(I), indexing="ij")
+        u = torch.from_numpy(uu.reshape(-1)); i = torch.from_numpy(ii.reshape(-1))
+        with torch.no_grad():
+            out[tag + "__scores"] = m(u, i).numpy().reshape(U, I)
+            out[tag + "__scores64"] = f64(m)(u, i).numpy().reshape(U, I)
+        out.update(sd_np(m, tag + "__"))
+        out[tag + "__cfg"] = np.array([factor, layers])
+        print("G2b %-7s |score| mean %.3f f32-f64 %.3g" % (tag, np.abs(out[tag + "__scores64"]).mean(),
+                                                           np.abs(out[tag + "__scores"] - out[tag + "__scores64"]).max()))
+    np.savez_compressed(os.path.join(OUT, "g2b_other_shapes.npz"), **out)
+
+
+# ---------------------------------------------------------------------------
 # G2r  NCFRating (sigmoid*4+1 epilogue) small + slice of the real GMF-Rating.pth
 # ---------------------------------------------------------------------------
 def g2r_rating():
@@ -327,8 +350,13 @@ def g5_metrics():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                      # regenerate only the named fixtures, e.g. `make_golden.py g2b_other_shapes`
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+        sys.exit(0)
     g1_gmf_real()
     g2_neumf_small()
+    g2b_other_shapes()
     g2r_rating()
     g3_autorec()
     g4_hybrid()

@@ -71,6 +71,31 @@ def test_g2_small_models_pairs_matrix_topk(g2, tag):
         assert (gap <= 1e-5 * np.abs(rv[r, c]) + 1e-6).all()
 
 
+@pytest.mark.parametrize("tag", ["f16l2", "f64l3", "f8l4", "f128l1", "f64gmf"])
+def test_g2b_other_tower_shapes_run_on_the_unfused_hip_path(g2b, tag):
+    """factor_num / num_layers other than the shipped 32 x 3 (ncf-embedding.ipynb sweeps 8..128)."""
+    from recommender_amd.helpers import NCF
+    sd = golden_sd(g2b, tag)
+    factor, layers = (int(v) for v in g2b[tag + "__cfg"])
+    has_g = "embed_user_GMF.weight" in sd; has_m = "embed_user_MLP.weight" in sd
+    name = "NeuMF-end" if has_g and has_m else ("GMF" if has_g else "MLP")
+    ref = g2b[tag + "__scores"]
+    U, I = ref.shape
+    m = NCF(U, I, factor, layers, 0.1, name)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.eval().cuda()
+    uu, ii = np.meshgrid(np.arange(U), np.arange(I), indexing="ij")
+    s = m(torch.from_numpy(uu.reshape(-1)).cuda(), torch.from_numpy(ii.reshape(-1)).cuda()).cpu().numpy().reshape(U, I)
+    assert_close(s, ref, what=tag + " pairs"); assert_close(s, g2b[tag + "__scores64"], what=tag + " pairs vs fp64")
+    sm = m.score_matrix().cpu().numpy()
+    assert_close(sm, ref, what=tag + " matrix")
+    ids, vals = m.score_topk(torch.arange(5, 25).cuda(), 7, torch.arange(3, 50).cuda())
+    oid, oval = O.topk_rows(sm[5:25, 3:50], 7)
+    assert np.array_equal(ids.cpu().numpy(), oid) and np.array_equal(vals.cpu().numpy(), oval)
+    with pytest.raises(IndexError):
+        m(torch.tensor([U]).cuda(), torch.tensor([0]).cuda())
+
+
 def test_g2_subset_users_and_candidates(g2):
     sd = golden_sd(g2, "end")
     m = _ncf_from_sd(sd)

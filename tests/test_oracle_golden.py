@@ -72,6 +72,14 @@ def test_g2_small_models(g2):
         assert np.array_equal(ids[untied], ref_ids[untied])
 
 
+def test_g2b_other_tower_shapes(g2b):
+    for tag in ("f16l2", "f64l3", "f8l4", "f128l1", "f64gmf"):
+        sd = golden_sd(g2b, tag)
+        ref = g2b[tag + "__scores"]
+        assert_close(O.ncf_score_all(sd, np.arange(ref.shape[0])), ref, what=tag)
+        assert_close(O.ncf_score_all(sd, np.arange(ref.shape[0]), np.float64), g2b[tag + "__scores64"], rtol=1e-12, atol=1e-12, what=tag)
+
+
 def test_g2_key_lists(g2):
     assert len(g2["key_list_end"]) == 12 and len(g2["key_list_pre"]) == 26
     sd = golden_sd(g2, "pre")
