@@ -73,3 +73,8 @@ def g5():
 @pytest.fixture(scope="session")
 def g2b():
     return load_golden("g2b_other_shapes.npz")
+
+
+@pytest.fixture(scope="session")
+def g6():
+    return load_golden("g6_files.npz")

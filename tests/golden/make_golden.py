@@ -349,6 +349,56 @@ def g5_metrics():
     print("G5 hit mean %.3f ndcg mean %.4f" % (hr.mean(), nd.mean()))
 
 
+# ---------------------------------------------------------------------------
+# G6  data files either side of the path: ratings.dat -> dense matrix, train.rating / test.negative parsers
+# ---------------------------------------------------------------------------
+def g6_files():
+    import pandas as pd
+    fdir = os.path.join(OUT, "files"); os.makedirs(fdir, exist_ok=True)
+    rng = np.random.default_rng(6)
+    # ratings.dat with gaps in both id spaces and one duplicated (user, item) pair (last occurrence wins in the reference loop)
+    raw_users = np.sort(rng.choice(np.arange(1, 60), 23, replace=False)); raw_items = np.sort(rng.choice(np.arange(1, 200), 41, replace=False))
+    rows = []
+    for u in raw_users:
+        for it in rng.choice(raw_items, rng.integers(3, 12), replace=False):
+            rows.append((int(u), int(it), int(rng.integers(1, 6)), int(978300000 + rng.integers(0, 10 ** 6))))
+    rows.append((rows[5][0], rows[5][1], 6 - rows[5][2], 978400000))
+    with open(os.path.join(fdir, "mini_ratings.dat"), "w", encoding="latin-1") as f:
+        for r in rows:
+            f.write("%d::%d::%d::%d\n" % r)
+    cfg = {"user_num": 25, "item_num": 44}            # a little larger than the id spaces, as AUTOREC_CONFIG is fixed in the reference
+    tree = ast.parse(open(os.path.join(REF, "src/api/core/data_loader.py")).read())
+    ns = {"np": np, "pd": pd, "torch": torch, "os": os, "Optional": __import__("typing").Optional, "AUTOREC_CONFIG": cfg}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in ("_create_matrix_from_ratings", "_load_training_file"):
+            exec(compile(ast.Module([node], []), "data_loader.py", "exec"), ns)
+    df = pd.read_csv(os.path.join(fdir, "mini_ratings.dat"), sep="::", header=None, names=["user_id", "item_id", "rating", "timestamp"],
+                     engine="python", encoding="latin-1",
+                     dtype={"user_id": np.int32, "item_id": np.int32, "rating": np.float32, "timestamp": np.int32})
+    mat = ns["_create_matrix_from_ratings"](df)
+    # NCF-format files
+    U, I = 19, 37
+    train = sorted({(int(rng.integers(0, U)), int(rng.integers(0, I))) for _ in range(160)})
+    train.append((U - 1, I - 1))
+    with open(os.path.join(fdir, "mini.train.rating"), "w") as f:
+        for u, it in train:
+            f.write("%d\t%d\n" % (u, it))
+    with open(os.path.join(fdir, "mini.test.negative"), "w") as f:
+        for c in range(31):
+            u, it = int(rng.integers(0, U)), int(rng.integers(0, I))
+            f.write("(%d, %d)\t" % (u, it) + "\t".join(str(int(x)) for x in rng.integers(0, I, 9)) + "\n")
+    sys.path.insert(0, os.path.join(REF, "src", "ncf"))
+    from utils.load_all_data import load_all_data
+    train_data, test_data, user_num, item_num, train_mat = load_all_data(os.path.join(fdir, "mini.train.rating"),
+                                                                         os.path.join(fdir, "mini.test.negative"))
+    binmat = ns["_load_training_file"](os.path.join(fdir, "mini.train.rating"))
+    np.savez_compressed(os.path.join(OUT, "g6_files.npz"), ratings_matrix=mat, cfg=np.array([cfg["user_num"], cfg["item_num"]]),
+                        train_data=np.array(train_data, np.int32), test_data=np.array(test_data, np.int32),
+                        user_num=np.int64(user_num), item_num=np.int64(item_num), train_mat=np.asarray(train_mat.todense(), np.float32),
+                        binary_matrix=binmat)
+    print("G6 ratings matrix nnz %d, test_data %s, user_num %d item_num %d" % (np.count_nonzero(mat), np.array(test_data).shape, user_num, item_num))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                      # regenerate only the named fixtures, e.g. `make_golden.py g2b_other_shapes`
         for fn in sys.argv[1:]:
@@ -361,6 +411,7 @@ if __name__ == "__main__":
     g3_autorec()
     g4_hybrid()
     g5_metrics()
+    g6_files()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print("%-24s %8.1f KB" % (f, os.path.getsize(os.path.join(OUT, f)) / 1024))

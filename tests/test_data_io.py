@@ -1,0 +1,54 @@
+"""File readers / matrix builders against what the reference's own loaders produced from the same files (fixture G6)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from recommender_amd import data_io as D
+
+FILES = os.path.join(GOLDEN, "files")
+
+
+def test_ratings_dat_to_dense_matrix(g6):
+    user_num, item_num = (int(v) for v in g6["cfg"])
+    mat = D.load_training_matrix(os.path.join(FILES, "mini_ratings.dat"), user_num, item_num)
+    assert mat.dtype == np.float32 and np.array_equal(mat, g6["ratings_matrix"])      # incl. re-indexing and last-duplicate-wins
+    u, i, r = D.read_ratings_dat(os.path.join(FILES, "mini_ratings.dat"))
+    assert len(u) == len(i) == len(r) and r.min() >= 1 and r.max() <= 5
+    # already 0-based contiguous ids are left alone
+    m2 = D.build_rating_matrix(np.array([0, 1, 2]), np.array([0, 1, 2]), np.array([3., 4., 5.]), 4, 4)
+    assert m2[2, 2] == 5 and m2.sum() == 12
+    # out-of-range entries are dropped, not wrapped
+    m3 = D.build_rating_matrix(np.array([0, 1, 2]), np.array([0, 1, 2]), np.array([3., 4., 5.]), 2, 2)
+    assert m3.shape == (2, 2) and m3.sum() == 7
+
+
+def test_train_rating_and_test_negative(g6, tmp_path):
+    pairs = D.read_pairs_tsv(os.path.join(FILES, "mini.train.rating"))
+    assert np.array_equal(pairs, g6["train_data"])
+    assert pairs[:, 0].max() + 1 == int(g6["user_num"]) and pairs[:, 1].max() + 1 == int(g6["item_num"])
+    dense = D.binary_matrix_from_pairs(pairs, int(g6["user_num"]), int(g6["item_num"]))
+    assert np.array_equal(dense, g6["train_mat"])
+    assert np.array_equal(D.binary_matrix_from_pairs(pairs, 25, 44), g6["binary_matrix"])
+    users, items = D.read_test_negative(os.path.join(FILES, "mini.test.negative"))
+    assert items.shape == (31, 10)
+    assert np.array_equal(D.test_cases_as_pairs(users, items), g6["test_data"])
+    out = tmp_path / "rt.test.negative"
+    D.write_test_negative(out, users, items)
+    assert open(out).read() == open(os.path.join(FILES, "mini.test.negative")).read()
+
+
+def test_test_negative_never_evaluates_file_content(tmp_path):
+    evil = tmp_path / "evil.test.negative"
+    evil.write_text("__import__('os').system('true')\t1\t2\n")
+    with pytest.raises(ValueError, match="expected"):
+        D.read_test_negative(evil)
+    ragged = tmp_path / "ragged.test.negative"
+    ragged.write_text("(1, 2)\t3\t4\n(1, 3)\t5\n")
+    with pytest.raises(ValueError, match="different numbers"):
+        D.read_test_negative(ragged)
+    empty = tmp_path / "empty.test.negative"
+    empty.write_text("")
+    u, it = D.read_test_negative(empty)
+    assert u.shape == (0,) and it.shape[0] == 0
