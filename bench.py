@@ -95,7 +95,8 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # under torch.distributed.run (also at N = 1)
+    if launched:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
 
@@ -115,7 +116,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if launched:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -136,7 +137,7 @@ def main():
     tile_ms = float(np.mean(list(ms)[: n.value])) if n.value else float("nan")
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if launched:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -167,7 +168,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(model, ids.cpu().numpy(), vals.cpu().numpy())
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if launched:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -22,9 +22,9 @@ def all_gather_topk(ids, vals, counts=None, group=None):
     counts: list of per-rank row counts (needed when they differ: ranks pad to the maximum and the
     padding is dropped after the gather).  Equal counts use all_gather_into_tensor directly.
     """
-    world = dist.get_world_size(group)
-    if world == 1:
+    if not dist.is_initialized():
         return ids, vals
+    world = dist.get_world_size(group)
     k = ids.shape[1]
     if counts is None:
         counts = [ids.shape[0]] * world
@@ -53,7 +53,7 @@ def sharded_score_topk(model, k, total_users=None, candidates=None, group=None, 
     U = tower.n_users if total_users is None else int(total_users)
     start, count = shard_range(U, rank, world)
     ids, vals = tower.score_topk((start, count), k, candidates, None, check_ids=False, ws=ws, out=out)
-    if world == 1:
+    if not dist.is_initialized():
         return ids, vals
     counts = [shard_range(U, r, world)[1] for r in range(world)]
     return all_gather_topk(ids, vals, counts, group)
