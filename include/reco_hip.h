@@ -74,18 +74,27 @@ int reco_neumf_gather(const float* Eu_g, const float* Ei_g, const float* Eu_m, c
  *                                           src/hybridautorecncf/evaluate_hybridautorecncf_rating.py:78-106
  * a_rows (nullable, int64[M]) gathers A rows: row(m) = a_rows[m], else m.  lda/ldw/ldc are row
  * strides in floats (so W may be a column block of a wider matrix).
+ * ws (nullable) enables split-K for small output grids with a long K (AutoRec encoder, Hybrid
+ * encoders): K slices are reduced in slice order, so results stay bitwise reproducible.
  * ---------------------------------------------------------------------------------------- */
+#define RECO_LINEAR_A_TRANSPOSED 1   /* A is stored [K, M] with row stride lda: the item-vector batch X = R^T of
+                                       inference_engine.py:230 / helper.py:283 is read straight out of R [users, items] */
+#define RECO_LINEAR_BIAS_PER_ROW 2   /* bias[m] instead of bias[n]: R_hat^T = Wd H^T + bd, no transposed copy */
+size_t reco_linear_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int reco_linear_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_t a_row_limit, int64_t M,
                     const float* W, int64_t ldw, const float* bias, int64_t N, int64_t K,
-                    int act, float lo, float hi, float* C, int64_t ldc, void* stream);
+                    int act, float lo, float hi, float* C, int64_t ldc, int flags,
+                    void* ws, size_t ws_bytes, void* stream);
 
 /* AutoRec forward: out = act( sigmoid(X We^T + be) Wd^T + bd )        src/autorec/utils/model.py:31-33
  * X [B, n_in], We [hidden, n_in], Wd [n_in, hidden], hidden_ws [B, hidden] (caller scratch),
  * out [B, n_in].  act = RECO_ACT_NONE (the module's forward) or RECO_ACT_CLAMP with lo/hi
  * (the engines' clamp(1,5), inference_engine.py:232, helper.py:289). */
+size_t reco_autorec_workspace_bytes(int64_t B, int64_t n_in, int64_t hidden);
 int reco_autorec_forward(const float* X, int64_t B, const float* We, const float* be,
                          const float* Wd, const float* bd, int64_t n_in, int64_t hidden,
-                         int act, float lo, float hi, float* hidden_ws, float* out, void* stream);
+                         int act, float lo, float hi, float* hidden_ws, float* out,
+                         void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K-b  fused scoring tower (NeuMF, MLP-only, GMF-only, Hybrid head)

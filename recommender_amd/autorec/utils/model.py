@@ -70,10 +70,15 @@ class AutoRec(nn.Module):
         result is transposed back, so R_hat[u, i] = forward(train[:, i])[u].
         """
         device = self._device_of(train_matrix)
-        m = train_matrix.to(device=device, dtype=torch.float32)
-        if self.item_based:
-            return self.reconstruct(m.t().contiguous(), clamp).t().contiguous()
-        return self.reconstruct(m.contiguous(), clamp)
+        m = train_matrix.to(device=device, dtype=torch.float32).contiguous()
+        if not self.item_based:
+            return self.reconstruct(m, clamp)
+        # no transposed copies: the encoder reads R as the [K = users, M = items] operand, and the decoder is run with
+        # its operands swapped, R_hat^T[u, i] = Wd[u, :] . H[i, :] + bd[u], which lands directly in [users, items]
+        we, be, wd, bd = self._weights(device)[1]
+        h = ops.linear(m, we, be, act="sigmoid", x_transposed=True)
+        act = (None, 0.0, 0.0) if clamp is None else ("clamp", float(clamp[0]), float(clamp[1]))
+        return ops.linear(wd, h, bd, act=act[0], lo=act[1], hi=act[2], bias_per_row=True)
 
     def recommend_topk(self, train_matrix, k=10, users=None, mask_seen=True, clamp=(1.0, 5.0)):
         """Per-user top-k of the reconstruction, seen items pushed to -1e10 as helper.py:313.
@@ -97,8 +102,8 @@ class AutoRec(nn.Module):
             raise ValueError("cache_hidden is for the item-based model")
         device = self._device_of(train_matrix)
         sig, (we, be, wd, bd), extra = self._weights(device)
-        x = train_matrix.to(device=device, dtype=torch.float32).t().contiguous()
-        extra["H"] = ops.linear(x, we, be, act="sigmoid")
+        x = train_matrix.to(device=device, dtype=torch.float32).contiguous()
+        extra["H"] = ops.linear(x, we, be, act="sigmoid", x_transposed=True)
         return extra["H"]
 
     def predict_user(self, user_id, item_ids=None, clamp=(1.0, 5.0)):

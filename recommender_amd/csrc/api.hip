@@ -98,16 +98,27 @@ struct ProfScope {
 // ---------------------------------------------------------------------------------------------
 extern "C" int reco_linear_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_t a_row_limit, int64_t M,
                                const float* W, int64_t ldw, const float* bias, int64_t N, int64_t K,
-                               int act, float lo, float hi, float* C, int64_t ldc, void* stream)
+                               int act, float lo, float hi, float* C, int64_t ldc, int flags,
+                               void* ws, size_t ws_bytes, void* stream)
 {
     RECO_REQUIRE(act >= RECO_ACT_NONE && act <= RECO_ACT_RATING, "linear: unknown activation %d", act);
+    RECO_REQUIRE((flags & ~3) == 0, "linear: unknown flags %d", flags);
     return launch_linear_f32(A, lda, a_rows, a_row_limit, M, W, ldw, bias, N, K, act, lo, hi, C, ldc, nullptr,
-                             (hipStream_t)stream);
+                             ws, ws_bytes, (hipStream_t)stream, flags);
+}
+
+extern "C" size_t reco_linear_workspace_bytes(int64_t M, int64_t N, int64_t K) { return linear_workspace_bytes(M, N, K); }
+
+extern "C" size_t reco_autorec_workspace_bytes(int64_t B, int64_t n_in, int64_t hidden)
+{
+    const size_t a = linear_workspace_bytes(B, hidden, n_in), b = linear_workspace_bytes(B, n_in, hidden);
+    return a > b ? a : b;
 }
 
 extern "C" int reco_autorec_forward(const float* X, int64_t B, const float* We, const float* be,
                                     const float* Wd, const float* bd, int64_t n_in, int64_t hidden,
-                                    int act, float lo, float hi, float* hidden_ws, float* out, void* stream)
+                                    int act, float lo, float hi, float* hidden_ws, float* out,
+                                    void* ws, size_t ws_bytes, void* stream)
 {
     if (B <= 0) return RECO_OK;
     RECO_REQUIRE(X && We && be && Wd && bd && hidden_ws && out, "autorec_forward: null pointer");
@@ -115,10 +126,10 @@ extern "C" int reco_autorec_forward(const float* X, int64_t B, const float* We, 
     RECO_REQUIRE(act == RECO_ACT_NONE || act == RECO_ACT_CLAMP, "autorec_forward: act must be NONE or CLAMP");
     hipStream_t s = (hipStream_t)stream;
     int rc = launch_linear_f32(X, n_in, nullptr, 0, B, We, n_in, be, hidden, n_in, RECO_ACT_SIGMOID, 0.f, 0.f,
-                               hidden_ws, hidden, nullptr, s);
+                               hidden_ws, hidden, nullptr, ws, ws_bytes, s);
     if (rc) return rc;
     return launch_linear_f32(hidden_ws, hidden, nullptr, 0, B, Wd, hidden, bd, n_in, hidden, act, lo, hi, out, n_in,
-                             nullptr, s);
+                             nullptr, ws, ws_bytes, s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -158,12 +169,12 @@ static int tower_project(const reco_tower* t, const float* u_rows, const int64_t
     const int dm = t->d.dm;
     if (U > 0) {
         int rc = launch_linear_f32(u_rows, dm, u_idx, u_limit, U, t->d.W[0], 2 * dm, t->d.b[0], H1, dm, RECO_ACT_NONE,
-                                   0.f, 0.f, P, H1, t->oob, s);
+                                   0.f, 0.f, P, H1, t->oob, nullptr, 0, s);
         if (rc) return rc;
     }
     if (N > 0) {
         int rc = launch_linear_f32(i_rows, dm, i_idx, i_limit, N, t->d.W[0] + dm, 2 * dm, nullptr, H1, dm,
-                                   RECO_ACT_NONE, 0.f, 0.f, Q, H1, t->oob, s);
+                                   RECO_ACT_NONE, 0.f, 0.f, Q, H1, t->oob, nullptr, 0, s);
         if (rc) return rc;
     }
     return RECO_OK;

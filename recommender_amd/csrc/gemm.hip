@@ -31,6 +31,11 @@ struct LinArgs {
     float* C;
     int64_t ldc;
     int32_t* oob;
+    int splits;            // split-K: block b works on K slice b / tiles of k_per_split (multiple of BK) columns
+    int64_t k_per_split;
+    float* partial;        // [splits][M][N] raw accumulators when splits > 1
+    int a_trans;           // A is stored [K, M] (row stride lda): C = act(A^T W^T + bias)
+    int bias_rows;         // bias indexed by output row m instead of column n
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float lo, float hi)
@@ -71,7 +76,7 @@ __device__ __forceinline__ f32x4 load_k4(const float* row, int64_t k, int64_t K)
 // K is consumed in BK = 32 tiles through a double-buffered LDS image: the global loads of tile t+1 are issued before
 // the MFMAs of tile t and written to the other buffer after them -- one barrier per tile, no branch in the steady state
 // (rows past M / N are clamped to the last row and discarded at the store; only the ragged last K tile is guarded).
-template <int BM, int BN, int VEC>
+template <int BM, int BN, int VEC, bool AT>
 __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
 {
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -87,8 +92,13 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
     const int i = lane & 31, h = lane >> 5;
 
     const int64_t tiles_n = (a.N + BN - 1) / BN;
-    const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * BM;
-    const int64_t n0 = (int64_t)(blockIdx.x % tiles_n) * BN;
+    const int64_t tiles = tiles_n * ((a.M + BM - 1) / BM);
+    const int64_t tile = blockIdx.x % tiles;
+    const int split = (int)(blockIdx.x / tiles);
+    const int64_t m0 = (tile / tiles_n) * BM;
+    const int64_t n0 = (tile % tiles_n) * BN;
+    const int64_t kb = split * a.k_per_split;                                   // this block's K slice [kb, ke)
+    const int64_t ke = kb + a.k_per_split < a.K ? kb + a.k_per_split : a.K;
 
     // staging assignment: thread -> (row r = tid/8 + 32*s, float4 column c = tid%8)
     const int sr = tid >> 3, sc = tid & 7;
@@ -96,6 +106,7 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
     const float* wrow[RB];
 #pragma unroll
     for (int s = 0; s < RA; ++s) {
+        if constexpr (AT) { arow[s] = nullptr; continue; }
         int64_t m = m0 + sr + 32 * s;
         if (m >= a.M) m = a.M - 1;
         int64_t r = m;
@@ -106,13 +117,13 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
                 r = r < 0 ? 0 : a.a_row_limit - 1;
             }
         }
-        arow[s] = a.A + r * a.lda + 4 * sc;
+        arow[s] = a.A + r * a.lda + kb + 4 * sc;
     }
 #pragma unroll
     for (int s = 0; s < RB; ++s) {
         int64_t n = n0 + sr + 32 * s;
         if (n >= a.N) n = a.N - 1;
-        wrow[s] = a.W + n * a.ldw + 4 * sc;
+        wrow[s] = a.W + n * a.ldw + kb + 4 * sc;
     }
 
     f32x16 acc[TM][TN];
@@ -123,29 +134,68 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-    const int64_t nt = (a.K + BK - 1) / BK;
-    const bool ragged = (a.K % BK) != 0;
+    const int64_t Kl = ke - kb;                                                 // local K (pointers are already offset by kb)
+    const int64_t nt = (Kl + BK - 1) / BK;
+    const bool ragged = (Kl % BK) != 0;
     f32x4 ra[RA], rb[RB];
+    // transposed A ([K, M] storage): a k-row of the tile is BM contiguous floats; thread -> (k row tk + KPP*s, float4 tc along m)
+    constexpr int CPR = BM / 4, KPP = 256 / CPR;
+    const int tc = tid % CPR, tk = tid / CPR;
+    const bool at_vec = AT && (a.lda % 4 == 0) && ((uintptr_t)a.A % 16 == 0) && (m0 + BM <= a.M);
 
+    auto load_a_trans = [&](int64_t k0, bool guard_k) {
+#pragma unroll
+        for (int s = 0; s < RA; ++s) {
+            const int64_t k = k0 + tk + KPP * s;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (!guard_k || k < Kl) {
+                const float* src = a.A + (kb + k) * a.lda + m0 + 4 * tc;
+                if (at_vec) {
+                    v = *reinterpret_cast<const f32x4*>(src);
+                } else {
+                    const int64_t left = a.M - (m0 + 4 * tc);
+                    if (left > 0) v.x = src[0];
+                    if (left > 1) v.y = src[1];
+                    if (left > 2) v.z = src[2];
+                    if (left > 3) v.w = src[3];
+                }
+            }
+            ra[s] = v;
+        }
+    };
     auto load_tile = [&](int64_t t) {
         const int64_t k0 = t * BK;
         if (ragged && t == nt - 1) {
+            if constexpr (AT) load_a_trans(k0, true);
+            else {
 #pragma unroll
-            for (int s = 0; s < RA; ++s) ra[s] = load_k4<1, true>(arow[s], k0, a.K - 4 * sc);
+                for (int s = 0; s < RA; ++s) ra[s] = load_k4<1, true>(arow[s], k0, Kl - 4 * sc);
+            }
 #pragma unroll
-            for (int s = 0; s < RB; ++s) rb[s] = load_k4<1, true>(wrow[s], k0, a.K - 4 * sc);
+            for (int s = 0; s < RB; ++s) rb[s] = load_k4<1, true>(wrow[s], k0, Kl - 4 * sc);
         } else {
+            if constexpr (AT) load_a_trans(k0, false);
+            else {
 #pragma unroll
-            for (int s = 0; s < RA; ++s) ra[s] = load_k4<VEC, false>(arow[s], k0, a.K);
+                for (int s = 0; s < RA; ++s) ra[s] = load_k4<VEC, false>(arow[s], k0, Kl);
+            }
 #pragma unroll
-            for (int s = 0; s < RB; ++s) rb[s] = load_k4<VEC, false>(wrow[s], k0, a.K);
+            for (int s = 0; s < RB; ++s) rb[s] = load_k4<VEC, false>(wrow[s], k0, Kl);
         }
     };
     auto store_tile = [&](int buf) {
         float* s_a = smem + buf * BUF;
         float* s_b = s_a + BM * LS;
+        if constexpr (AT) {   // transposing store: [m][k] image from k-major registers
 #pragma unroll
-        for (int s = 0; s < RA; ++s) *reinterpret_cast<f32x4*>(s_a + (sr + 32 * s) * LS + 4 * sc) = ra[s];
+            for (int s = 0; s < RA; ++s) {
+                float* d = s_a + (4 * tc) * LS + tk + KPP * s;
+                d[0] = ra[s].x; d[LS] = ra[s].y; d[2 * LS] = ra[s].z; d[3 * LS] = ra[s].w;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < RA; ++s) *reinterpret_cast<f32x4*>(s_a + (sr + 32 * s) * LS + 4 * sc) = ra[s];
+        }
 #pragma unroll
         for (int s = 0; s < RB; ++s) *reinterpret_cast<f32x4*>(s_b + (sr + 32 * s) * LS + 4 * sc) = rb[s];
     };
@@ -182,41 +232,65 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
     for (int tn = 0; tn < TN; ++tn) {
         const int64_t n = n0 + wn * (BN / 2) + tn * 32 + i;
         if (n >= a.N) continue;
-        const float bv = a.bias ? a.bias[n] : 0.f;
+        const float bv = (a.bias && !a.bias_rows) ? a.bias[n] : 0.f;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t m = m0 + wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m < a.M) a.C[m * a.ldc + n] = apply_act(acc[tm][tn][r] + bv, a.act, a.lo, a.hi);
+                if (m >= a.M) continue;
+                if (a.splits > 1) a.partial[((int64_t)split * a.M + m) * a.N + n] = acc[tm][tn][r];
+                else a.C[m * a.ldc + n] = apply_act(acc[tm][tn][r] + ((a.bias && a.bias_rows) ? a.bias[m] : bv), a.act, a.lo, a.hi);
             }
         }
     }
 }
 
-template <int BM, int BN, int VEC>
+// split-K epilogue: slices are added in slice order (deterministic), then bias + activation
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(LinArgs a)
+{
+    const int64_t total = a.M * a.N;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        float v = a.partial[e];
+        for (int sp = 1; sp < a.splits; ++sp) v += a.partial[(int64_t)sp * total + e];
+        const int64_t m = e / a.N, n = e - m * a.N;
+        a.C[m * a.ldc + n] = apply_act(v + (a.bias ? a.bias[a.bias_rows ? m : n] : 0.f), a.act, a.lo, a.hi);
+    }
+}
+
+template <int BM, int BN, int VEC, bool AT>
 int launch_v(const LinArgs& a, hipStream_t s)
 {
     constexpr size_t lds = (size_t)2 * (BM + BN) * LS * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        RECO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel<BM, BN, VEC>),
+        RECO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel<BM, BN, VEC, AT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    const int64_t blocks = ceil_div64(a.M, BM) * ceil_div64(a.N, BN);
+    const int64_t blocks = ceil_div64(a.M, BM) * ceil_div64(a.N, BN) * a.splits;
     RECO_REQUIRE(blocks < (1ll << 31), "linear grid too large");
-    hipLaunchKernelGGL((linear_kernel<BM, BN, VEC>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((linear_kernel<BM, BN, VEC, AT>), dim3((unsigned)blocks), dim3(256), lds, s, a);
     RECO_CHECK_LAUNCH();
+    if (a.splits > 1) {
+        const int64_t rb = ceil_div64(a.M * a.N, 256);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(rb < 4096 ? rb : 4096)), dim3(256), 0, s, a);
+        RECO_CHECK_LAUNCH();
+    }
     return RECO_OK;
 }
 
 template <int BM, int BN>
 int launch_t(const LinArgs& a, int vec, hipStream_t s)
 {
-    if (vec == 4) return launch_v<BM, BN, 4>(a, s);
-    if (vec == 2) return launch_v<BM, BN, 2>(a, s);
-    return launch_v<BM, BN, 1>(a, s);
+    if (a.a_trans) {
+        if (vec == 4) return launch_v<BM, BN, 4, true>(a, s);
+        if (vec == 2) return launch_v<BM, BN, 2, true>(a, s);
+        return launch_v<BM, BN, 1, true>(a, s);
+    }
+    if (vec == 4) return launch_v<BM, BN, 4, false>(a, s);
+    if (vec == 2) return launch_v<BM, BN, 2, false>(a, s);
+    return launch_v<BM, BN, 1, false>(a, s);
 }
 
 // rough utilisation model: larger tiles amortise LDS traffic better, but the grid must cover the 256 CUs
@@ -230,22 +304,61 @@ double tile_score(int64_t M, int64_t N, int bm, int bn, double tile_eff)
 
 }  // namespace
 
+// K slices so that a small output grid still fills the chip; 0 workspace -> no split
+static int choose_splits(int64_t blocks, int64_t K)
+{
+    if (blocks >= 384 || K < 1024) return 1;
+    int64_t sp = ceil_div64(768, blocks);
+    const int64_t by_k = K / 512;
+    if (sp > by_k) sp = by_k;
+    if (sp > 8) sp = 8;
+    return sp < 1 ? 1 : (int)sp;
+}
+
+size_t linear_workspace_bytes(int64_t M, int64_t N, int64_t K)
+{
+    if (M <= 0 || N <= 0) return 0;
+    // worst case over the tile shapes: the smallest grid (128x128) takes the most slices
+    const int sp = choose_splits(ceil_div64(M, 128) * ceil_div64(N, 128), K);
+    return sp > 1 ? align_up((size_t)sp * M * N * sizeof(float), 256) : 0;
+}
+
 int launch_linear_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_t a_row_limit, int64_t M,
                       const float* W, int64_t ldw, const float* bias, int64_t N, int64_t K,
-                      int act, float lo, float hi, float* C, int64_t ldc, int32_t* oob, hipStream_t s)
+                      int act, float lo, float hi, float* C, int64_t ldc, int32_t* oob,
+                      void* ws, size_t ws_bytes, hipStream_t s, int flags)
 {
     if (M <= 0 || N <= 0) return RECO_OK;
+    const bool at = (flags & RECO_LINEAR_A_TRANSPOSED) != 0;
     RECO_REQUIRE(K > 0, "linear: K must be positive");
     RECO_REQUIRE(A && W && C, "linear: null pointer");
-    RECO_REQUIRE(lda >= K && ldw >= K && ldc >= N, "linear: leading dimension smaller than the row");
-    LinArgs a{A, lda, a_rows, a_rows ? a_row_limit : M, M, W, ldw, bias, N, K, act, lo, hi, C, ldc, oob};
+    RECO_REQUIRE(lda >= (at ? M : K) && ldw >= K && ldc >= N, "linear: leading dimension smaller than the row");
+    RECO_REQUIRE(!(at && a_rows), "linear: row gather and transposed A cannot be combined");
+    LinArgs a{A, lda, a_rows, a_rows ? a_row_limit : M, M, W, ldw, bias, N, K, act, lo, hi, C, ldc, oob, 1, K, nullptr,
+              at ? 1 : 0, (flags & RECO_LINEAR_BIAS_PER_ROW) ? 1 : 0};
     int vec = 1;
-    if (lda % 4 == 0 && ldw % 4 == 0 && (uintptr_t)A % 16 == 0 && (uintptr_t)W % 16 == 0) vec = 4;
-    else if (lda % 2 == 0 && ldw % 2 == 0 && (uintptr_t)A % 8 == 0 && (uintptr_t)W % 8 == 0) vec = 2;
+    const bool a4 = at || (lda % 4 == 0 && (uintptr_t)A % 16 == 0), a2 = at || (lda % 2 == 0 && (uintptr_t)A % 8 == 0);
+    if (a4 && ldw % 4 == 0 && (uintptr_t)W % 16 == 0) vec = 4;
+    else if (a2 && ldw % 2 == 0 && (uintptr_t)W % 8 == 0) vec = 2;
     const double s11 = tile_score(M, N, 128, 128, 1.00), s12 = tile_score(M, N, 128, 64, 0.85);
     const double s21 = tile_score(M, N, 64, 128, 0.85), s22 = tile_score(M, N, 64, 64, 0.70);
-    if (s11 >= s12 && s11 >= s21 && s11 >= s22) return launch_t<128, 128>(a, vec, s);
-    if (s12 >= s21 && s12 >= s22) return launch_t<128, 64>(a, vec, s);
-    if (s21 >= s22) return launch_t<64, 128>(a, vec, s);
+    int bm = 64, bn = 64;
+    if (s11 >= s12 && s11 >= s21 && s11 >= s22) { bm = 128; bn = 128; }
+    else if (s12 >= s21 && s12 >= s22) { bm = 128; bn = 64; }
+    else if (s21 >= s22) { bm = 64; bn = 128; }
+    if (ws != nullptr) {
+        int sp = choose_splits(ceil_div64(M, bm) * ceil_div64(N, bn), K);
+        while (sp > 1 && (size_t)sp * M * N * sizeof(float) > ws_bytes) --sp;
+        if (sp > 1) {
+            a.splits = sp;
+            a.k_per_split = ceil_div64(ceil_div64(K, sp), BK) * BK;
+            a.splits = (int)ceil_div64(K, a.k_per_split);            // drop empty trailing slices
+            a.partial = static_cast<float*>(ws);
+            if (a.splits <= 1) { a.splits = 1; a.k_per_split = K; a.partial = nullptr; }
+        }
+    }
+    if (bm == 128 && bn == 128) return launch_t<128, 128>(a, vec, s);
+    if (bm == 128) return launch_t<128, 64>(a, vec, s);
+    if (bn == 128) return launch_t<64, 128>(a, vec, s);
     return launch_t<64, 64>(a, vec, s);
 }

@@ -53,7 +53,9 @@ struct TowerImage;  // opaque here
 
 int launch_linear_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_t a_row_limit, int64_t M,
                       const float* W, int64_t ldw, const float* bias, int64_t N, int64_t K,
-                      int act, float lo, float hi, float* C, int64_t ldc, int32_t* oob, hipStream_t s);
+                      int act, float lo, float hi, float* C, int64_t ldc, int32_t* oob,
+                      void* ws, size_t ws_bytes, hipStream_t s, int flags = 0);
+size_t linear_workspace_bytes(int64_t M, int64_t N, int64_t K);
 
 int launch_topk_rows(const float* scores, int64_t rows, int64_t N, int64_t ld, int k,
                      const uint8_t* exclude, int64_t ld_ex, int32_t* out_ids, float* out_vals,

@@ -49,12 +49,12 @@ class AutoEncoder(nn.Module):
                 nn.init.zeros_(m.bias)
 
     @staticmethod
-    def _run(seq, x, final_act):
+    def _run(seq, x, final_act, transposed=False):
         linears = [m for m in seq if isinstance(m, nn.Linear)]
         for n, lin in enumerate(linears):
             last = n + 1 == len(linears)
             x = ops.linear(x, _f32_on(lin.weight, x.device), _f32_on(lin.bias, x.device),
-                           act=(final_act if last else "relu"))
+                           act=(final_act if last else "relu"), x_transposed=(transposed and n == 0))
         return x
 
     def _prep(self, x):
@@ -64,9 +64,11 @@ class AutoEncoder(nn.Module):
         device = x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device())
         return x.to(device=device, dtype=torch.float32)
 
-    def encode(self, x):
+    def encode(self, x, transposed=False):
+        """transposed=True: x is [input_dim, batch] (e.g. the rating matrix itself for the item encoder) and is read
+        transposed by the first layer's GEMM instead of being copied."""
         src = x.device
-        z = self._run(self.encoder, self._prep(x), None)
+        z = self._run(self.encoder, self._prep(x), None, transposed)
         return z if z.device == src else z.to(src)
 
     def decode(self, z):
@@ -160,7 +162,7 @@ class HybridAutoRecNCF(nn.Module):
         device = rating_matrix.device if rating_matrix.is_cuda else torch.device("cuda", torch.cuda.current_device())
         R = rating_matrix.to(device=device, dtype=torch.float32).contiguous()
         zu = self.user_autorec.encode(R)
-        zi = self.item_autorec.encode(R.t().contiguous())
+        zi = self.item_autorec.encode(R, transposed=True)
         tower = self.ncf.score_matrix(zu, zi)
         if k is None:
             return tower.score_matrix(None, None, check_ids=False)

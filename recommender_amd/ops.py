@@ -102,8 +102,12 @@ def neumf_gather(eu_g, ei_g, eu_m, ei_m, user, item, check_ids=True, gmf_out=Non
 # ----------------------------------------------------------------------------------------------
 # K-c Linear / AutoRec
 # ----------------------------------------------------------------------------------------------
-def linear(x, weight, bias=None, act=None, lo=0.0, hi=0.0, out=None):
-    """act(x @ weight.T + bias) on the fp32 MFMA GEMM (nn.Linear + fused activation)."""
+def linear(x, weight, bias=None, act=None, lo=0.0, hi=0.0, out=None, x_transposed=False, bias_per_row=False):
+    """act(x @ weight.T + bias) on the fp32 MFMA GEMM (nn.Linear + fused activation).
+
+    x_transposed: x is given as [K, M] (the kernel reads it transposed: no .t().contiguous() copy);
+    bias_per_row: bias has M entries and is added per output row.
+    """
     if isinstance(x, torch.Tensor) and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1 \
             and x.stride(0) >= x.shape[1]:
         pass                                        # a column block of a wider row-major buffer is fine: lda = stride(0)
@@ -112,17 +116,24 @@ def linear(x, weight, bias=None, act=None, lo=0.0, hi=0.0, out=None):
     weight = _f32(weight, "weight", 2)
     if bias is not None:
         bias = _f32(bias, "bias", 1)
-    M, K = x.shape
+    K, M = x.shape if x_transposed else (x.shape[1], x.shape[0])
     N = weight.shape[0]
     if weight.shape[1] != K:
         raise ValueError("mat1 and mat2 shapes cannot be multiplied (%dx%d and %dx%d)" % (M, K, weight.shape[1], N))
+    if bias is not None and bias.numel() != (M if bias_per_row else N):
+        raise ValueError("bias has %d entries, expected %d" % (bias.numel(), M if bias_per_row else N))
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
     elif out.shape != (M, N) or out.dtype != torch.float32 or (N > 1 and out.stride(1) != 1):
         raise ValueError("out must be a float32 [%d, %d] tensor with unit inner stride" % (M, N))
+    L = _lib.lib()
+    nbytes = L.reco_linear_workspace_bytes(M, N, K)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
+    lda = x.stride(0) if x.shape[0] > 1 else x.shape[1]
+    flags = (1 if x_transposed else 0) | (2 if bias_per_row else 0)
     with torch.cuda.device(x.device):
-        check(_lib.lib().reco_linear_f32(_p(x), x.stride(0) if M > 1 else K, None, 0, M, _p(weight), K, _p(bias), N, K,
-                                         ACTS[act], lo, hi, _p(out), out.stride(0) if M > 1 else N, _stream(x.device)))
+        check(L.reco_linear_f32(_p(x), lda, None, 0, M, _p(weight), K, _p(bias), N, K, ACTS[act], lo, hi,
+                                _p(out), out.stride(0) if M > 1 else N, flags, _p(ws), nbytes, _stream(x.device)))
     return out
 
 
@@ -138,9 +149,12 @@ def autorec_forward(x, we, be, wd, bd, clamp=None):
     h = torch.empty((B, hidden), dtype=torch.float32, device=x.device)
     out = torch.empty((B, n_in), dtype=torch.float32, device=x.device)
     act, lo, hi = (ACT_NONE, 0.0, 0.0) if clamp is None else (ACT_CLAMP, float(clamp[0]), float(clamp[1]))
+    L = _lib.lib()
+    nbytes = L.reco_autorec_workspace_bytes(B, n_in, hidden)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
     with torch.cuda.device(x.device):
-        check(_lib.lib().reco_autorec_forward(_p(x), B, _p(we), _p(be), _p(wd), _p(bd), n_in, hidden, act, lo, hi,
-                                              _p(h), _p(out), _stream(x.device)))
+        check(L.reco_autorec_forward(_p(x), B, _p(we), _p(be), _p(wd), _p(bd), n_in, hidden, act, lo, hi,
+                                     _p(h), _p(out), _p(ws), nbytes, _stream(x.device)))
     return out
 
 

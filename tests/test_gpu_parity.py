@@ -253,7 +253,8 @@ def test_gather_kernels():
 def test_linear_shapes_and_epilogues():
     from recommender_amd import ops
     rng = np.random.default_rng(6)
-    for M, N, K in ((1, 1, 1), (7, 5, 3), (130, 70, 33), (300, 500, 6040 // 8), (257, 129, 100), (64, 64, 32), (100, 6, 3706 // 2 + 1)):
+    for M, N, K in ((1, 1, 1), (7, 5, 3), (130, 70, 33), (300, 500, 6040 // 8), (257, 129, 100), (64, 64, 32), (100, 6, 3706 // 2 + 1),
+                    (300, 70, 2500), (128, 256, 4099)):      # the last two take the split-K path
         x = rng.standard_normal((M, K)).astype(np.float32); w = rng.standard_normal((N, K)).astype(np.float32)
         b = rng.standard_normal(N).astype(np.float32)
         ref = x.astype(np.float64) @ w.astype(np.float64).T + b
@@ -263,3 +264,12 @@ def test_linear_shapes_and_epilogues():
             y = ops.linear(torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda(), torch.from_numpy(b).cuda(), act, -1.0, 2.0)
             err = np.abs(y.cpu().numpy() - f(ref))
             assert (err <= 4e-7 * scale + 1e-6).all(), (M, N, K, act, err.max())
+        # transposed-A operand and per-row bias give the same numbers as the plain form on transposed data
+        xt = torch.from_numpy(np.ascontiguousarray(x.T)).cuda()
+        y0 = ops.linear(torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda(), torch.from_numpy(b).cuda())
+        y1 = ops.linear(xt, torch.from_numpy(w).cuda(), torch.from_numpy(b).cuda(), x_transposed=True)
+        assert torch.equal(y0, y1), (M, N, K, "x_transposed")
+        bm = rng.standard_normal(M).astype(np.float32)
+        y2 = ops.linear(torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda(), torch.from_numpy(bm).cuda(), bias_per_row=True)
+        err = np.abs(y2.cpu().numpy() - (x.astype(np.float64) @ w.astype(np.float64).T + bm[:, None]))
+        assert (err <= 4e-7 * (scale + 1) + 1e-6).all(), (M, N, K, "bias_per_row")

@@ -67,6 +67,10 @@ def bench_autorec():
     ms = timeit(lambda: m.reconstruct(X))
     emit("linear_kernel x2 (AutoRec cfg3)", "X[3706,6040] -> 500 -> 6040, sigmoid + clamp fused", ms, "mfma", 2 * 2 * 3706 * 6040 * 500,
          "44.77 GFLOP per full reconstruction")
+    R = X.t().contiguous()
+    ms = timeit(lambda: m.recommend_topk(R, 10))
+    emit("AutoRec cfg3 end to end (reconstruct_all + seen-mask + top-10)", "R[6040,3706]", ms, "mfma", 2 * 2 * 3706 * 6040 * 500,
+         "44.77 GFLOP per full reconstruction", "users/s = %.3g" % (6040 / ms * 1e3))
     we, be = m.encoder[0].weight.detach(), m.encoder[0].bias.detach()
     wd, bd = m.decoder[0].weight.detach(), m.decoder[0].bias.detach()
     h = ops.linear(X, we, be, "sigmoid")
