@@ -25,12 +25,29 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
                                                           const int64_t* __restrict__ idx, int64_t B,
                                                           float* __restrict__ out, int32_t* oob)
 {
+    // 4 independent float4 per thread in flight (ids first, then rows, then the streaming stores): with one load per
+    // thread the kernel is latency-bound well below the HBM rate
+    constexpr int UNROLL = 4;
     const int64_t total = B * dim4;
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-        const int64_t b = t / dim4;
-        const int c = (int)(t - b * dim4);
-        const int64_t r = clamp_row(idx[b], rows, oob, c == 0);
-        reinterpret_cast<f32x4*>(out)[t] = reinterpret_cast<const f32x4*>(table)[r * dim4 + c];
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x; t0 < total; t0 += stride * UNROLL) {
+        int64_t r[UNROLL];
+        int c[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t t = t0 + u * stride;
+            const int64_t b = t < total ? t / dim4 : 0;
+            c[u] = (int)((t < total ? t : 0) - b * dim4);
+            r[u] = t < total ? clamp_row(idx[b], rows, oob, c[u] == 0) : 0;
+        }
+        f32x4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = reinterpret_cast<const f32x4*>(table)[r[u] * dim4 + c[u]];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t t = t0 + u * stride;
+            if (t < total) __builtin_nontemporal_store(v[u], reinterpret_cast<f32x4*>(out) + t);
+        }
     }
 }
 
@@ -49,32 +66,53 @@ struct FusedArgs {
 // out so that consecutive lanes write consecutive float4 of the outputs.
 __global__ __launch_bounds__(256) void neumf_gather_kernel(FusedArgs a)
 {
-    const int per_pair = (a.mlp_in ? 2 * a.m4 : 0);
+    constexpr int UNROLL = 4;
+    const int64_t stride = (int64_t)gridDim.x * 256;
     if (a.mlp_in) {
+        const int per_pair = 2 * a.m4;
         const int64_t total = a.B * per_pair;
-        for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-            const int64_t b = t / per_pair;
-            const int c = (int)(t - b * per_pair);
-            f32x4 v;
-            if (c < a.m4) {
-                const int64_t u = clamp_row(a.user[b], a.n_users, a.oob, c == 0);
-                v = reinterpret_cast<const f32x4*>(a.Eu_m)[u * a.m4 + c];
-            } else {
-                const int64_t i = clamp_row(a.item[b], a.n_items, a.oob, c == a.m4);
-                v = reinterpret_cast<const f32x4*>(a.Ei_m)[i * a.m4 + (c - a.m4)];
+        for (int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x; t0 < total; t0 += stride * UNROLL) {
+            const f32x4* src[UNROLL];
+            int64_t dst[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int64_t t = t0 + u * stride;
+                const bool ok = t < total;
+                const int64_t b = ok ? t / per_pair : 0;
+                const int c = ok ? (int)(t - b * per_pair) : 0;
+                dst[u] = ok ? b * a.ldm4 + c : -1;
+                if (c < a.m4) src[u] = reinterpret_cast<const f32x4*>(a.Eu_m) + clamp_row(a.user[b], a.n_users, a.oob, ok && c == 0) * a.m4 + c;
+                else src[u] = reinterpret_cast<const f32x4*>(a.Ei_m) + clamp_row(a.item[b], a.n_items, a.oob, ok && c == a.m4) * a.m4 + (c - a.m4);
             }
-            reinterpret_cast<f32x4*>(a.mlp_in)[b * a.ldm4 + c] = v;
+            f32x4 v[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) v[u] = *src[u];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                if (dst[u] >= 0) __builtin_nontemporal_store(v[u], reinterpret_cast<f32x4*>(a.mlp_in) + dst[u]);
         }
     }
     if (a.gmf_prod) {
         const int64_t total = a.B * a.g4;
-        for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-            const int64_t b = t / a.g4;
-            const int c = (int)(t - b * a.g4);
-            const int64_t u = clamp_row(a.user[b], a.n_users, a.oob, c == 0 && !a.mlp_in);
-            const int64_t i = clamp_row(a.item[b], a.n_items, a.oob, c == 0 && !a.mlp_in);
-            reinterpret_cast<f32x4*>(a.gmf_prod)[b * a.ldg4 + c] =
-                reinterpret_cast<const f32x4*>(a.Eu_g)[u * a.g4 + c] * reinterpret_cast<const f32x4*>(a.Ei_g)[i * a.g4 + c];
+        for (int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x; t0 < total; t0 += stride * UNROLL) {
+            const f32x4 *su[UNROLL], *si[UNROLL];
+            int64_t dst[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int64_t t = t0 + u * stride;
+                const bool ok = t < total;
+                const int64_t b = ok ? t / a.g4 : 0;
+                const int c = ok ? (int)(t - b * a.g4) : 0;
+                dst[u] = ok ? b * a.ldg4 + c : -1;
+                su[u] = reinterpret_cast<const f32x4*>(a.Eu_g) + clamp_row(a.user[b], a.n_users, a.oob, ok && c == 0 && !a.mlp_in) * a.g4 + c;
+                si[u] = reinterpret_cast<const f32x4*>(a.Ei_g) + clamp_row(a.item[b], a.n_items, a.oob, ok && c == 0 && !a.mlp_in) * a.g4 + c;
+            }
+            f32x4 vu[UNROLL], vi[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) { vu[u] = *su[u]; vi[u] = *si[u]; }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                if (dst[u] >= 0) __builtin_nontemporal_store(vu[u] * vi[u], reinterpret_cast<f32x4*>(a.gmf_prod) + dst[u]);
         }
     }
 }
