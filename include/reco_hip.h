@@ -123,7 +123,18 @@ typedef struct reco_tower_desc {
     const float* b_predict;  /* [1] */
     int32_t act;             /* RECO_ACT_NONE (logit, ncf_model.py:246-249) or RECO_ACT_RATING */
     float lo, hi;
+    int32_t precision;       /* RECO_PREC_F32 (default) or RECO_PREC_SPLIT_BF16X3, see below */
 } reco_tower_desc_t;
+
+/* How layers 2/3 of the MFMA path multiply.  Both accumulate in fp32 and meet the same parity gate (1e-5 relative
+ * against the reference's fp32 and fp64 outputs).
+ *   RECO_PREC_F32           fp32 operands on v_mfma_f32_32x32x2_f32: every product is the exact fp32 product.
+ *   RECO_PREC_SPLIT_BF16X3  each fp32 operand is split exactly into three bf16 pieces (hi + mid + lo) and the six
+ *                           cross terms down to 2^-24 relative are summed on v_mfma_f32_32x32x16_bf16; the dropped
+ *                           terms are below fp32 rounding.  Finite inputs only (an Inf operand yields NaN).  No
+ *                           counterpart in the reference, which computes in fp32 on the CPU. */
+#define RECO_PREC_F32           0
+#define RECO_PREC_SPLIT_BF16X3  1
 
 /* Packs the weights into the MFMA/LDS image and precomputes the layer-1 projections
  *   P[u] = W1[:, :dm] Eu_m[u] + b1,  Q[i] = W1[:, dm:] Ei_m[i]        (exact split of ncf_model.py:224-227 layer 1)

@@ -8,3 +8,5 @@ Package layout mirrors the reference's import paths for the hot path only:
 The arithmetic is in csrc/*.hip (libreco_hip.so, C ABI in include/reco_hip.h).
 """
 __version__ = "0.1.0"
+
+from .ops import set_tower_precision, tower_precision  # noqa: E402,F401

@@ -14,6 +14,8 @@ LIB_PATH = os.environ.get("RECO_HIP_LIB") or os.path.join(_HERE, "lib", "libreco
 
 OK, EINVAL, EHIP, ENOMEM, EINDEX = 0, -1, -2, -3, -4
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_CLAMP, ACT_RATING = 0, 1, 2, 3, 4
+PREC_F32, PREC_SPLIT_BF16X3 = 0, 1
+ABI_VERSION = 2
 
 
 class TowerDesc(Structure):
@@ -25,7 +27,7 @@ class TowerDesc(Structure):
         ("n_layers", c_int32), ("layer_out", c_int32 * 3),
         ("W", c_void_p * 3), ("b", c_void_p * 3),
         ("w_predict", c_void_p), ("b_predict", c_void_p),
-        ("act", c_int32), ("lo", c_float), ("hi", c_float),
+        ("act", c_int32), ("lo", c_float), ("hi", c_float), ("precision", c_int32),
     ]
 
 
@@ -79,6 +81,9 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
+        if handle.reco_abi_version() != ABI_VERSION:
+            raise ImportError("recommender_amd: %s has ABI version %d, this package needs %d; rebuild it (make -C recommender_amd/csrc)"
+                              % (LIB_PATH, handle.reco_abi_version(), ABI_VERSION))
         _lib = handle
     return _lib
 

@@ -20,6 +20,18 @@ int tower_launch_pairs(int G, int has_l3, const float* img, const float* P, cons
                        const float* EUg, const float* EIg, const int64_t* user, const int64_t* item,
                        int64_t n_users, int64_t n_items, int64_t B, float* out, float bp, int act,
                        float lo, float hi, int32_t* oob, hipStream_t s);
+// launchers defined in tower_split.hip (RECO_PREC_SPLIT_BF16X3)
+size_t tower_split_image_bytes(int has_l3);
+int tower_pack_split_image(const float* W2, const float* W3, int has_l3, const float* img, void* out, hipStream_t s);
+int tower_launch_tile_split(int G, int has_l3, const void* img, const float* P, const float* Q,
+                            const float* EUg, const float* EIg, const int64_t* users, const int64_t* cands,
+                            int64_t user_base, int64_t n_users, int64_t n_items, int64_t U, int64_t N,
+                            float* out, int64_t ld_out, float bp, int act, float lo, float hi, int32_t* oob,
+                            hipStream_t s);
+int tower_launch_pairs_split(int G, int has_l3, const void* img, const float* P, const float* Q,
+                             const float* EUg, const float* EIg, const int64_t* user, const int64_t* item,
+                             int64_t n_users, int64_t n_items, int64_t B, float* out, float bp, int act,
+                             float lo, float hi, int32_t* oob, hipStream_t s);
 int gmf_launch_pairs(const float* EUg, const float* EIg, const float* wp, const int64_t* user,
                      const int64_t* item, int64_t n_users, int64_t n_items, int64_t B, int G, float* out,
                      float bp, int act, float lo, float hi, int32_t* oob, hipStream_t s);
@@ -42,7 +54,7 @@ void reco_set_error(const char* fmt, ...)
 }
 
 extern "C" const char* reco_last_error(void) { return g_err; }
-extern "C" int reco_abi_version(void) { return 1; }
+extern "C" int reco_abi_version(void) { return 2; }
 
 // ---------------------------------------------------------------------------------------------
 // measurement hook: hipEvent pairs around the dominant kernel's launches
@@ -156,6 +168,7 @@ struct reco_tower {
     int has_l3;
     float bp;
     float* img;       // packed weight image [IMG_SIZE]
+    void* img_split;  // bf16x3 image (RECO_PREC_SPLIT_BF16X3 only)
     float* P;         // [n_users,128] layer-1 user projection (+ b1)
     float* Q;         // [n_items,128] layer-1 item projection
     int32_t* oob;     // device counter of clamped ids
@@ -180,10 +193,23 @@ static int tower_project(const reco_tower* t, const float* u_rows, const int64_t
     return RECO_OK;
 }
 
+static int run_pairs(const reco_tower* t, const float* P, const float* Q, const float* EUg, const float* EIg,
+                     const int64_t* user, const int64_t* item, int64_t n_users, int64_t n_items, int64_t B, float* out,
+                     int32_t* oob, hipStream_t s)
+{
+    const reco_tower_desc_t& d = t->d;
+    if (t->img_split)
+        return tower_launch_pairs_split(t->G, t->has_l3, t->img_split, P, Q, EUg, EIg, user, item, n_users, n_items, B,
+                                        out, t->bp, d.act, d.lo, d.hi, oob, s);
+    return tower_launch_pairs(t->G, t->has_l3, t->img, P, Q, EUg, EIg, user, item, n_users, n_items, B, out, t->bp,
+                              d.act, d.lo, d.hi, oob, s);
+}
+
 extern "C" void reco_tower_destroy(reco_tower_t* t)
 {
     if (!t) return;
     (void)hipFree(t->img);
+    (void)hipFree(t->img_split);
     (void)hipFree(t->P);
     (void)hipFree(t->Q);
     (void)hipFree(t->oob);
@@ -199,6 +225,8 @@ extern "C" int reco_tower_create(const reco_tower_desc_t* d, void* stream, reco_
     RECO_REQUIRE(d->n_users >= 0 && d->n_items >= 0, "tower_create: negative table size");
     RECO_REQUIRE(d->w_predict && d->b_predict, "tower_create: predict layer missing");
     RECO_REQUIRE(d->act == RECO_ACT_NONE || d->act == RECO_ACT_RATING, "tower_create: act must be NONE or RATING");
+    RECO_REQUIRE(d->precision == RECO_PREC_F32 || d->precision == RECO_PREC_SPLIT_BF16X3,
+                 "tower_create: unknown precision %d", d->precision);
     const bool tables = d->n_users > 0 && d->n_items > 0;
     if (tables && d->dg > 0) RECO_REQUIRE(d->user_gmf && d->item_gmf, "tower_create: GMF tables missing");
     if (tables && d->dm > 0) RECO_REQUIRE(d->user_mlp && d->item_mlp, "tower_create: MLP tables missing");
@@ -231,6 +259,8 @@ extern "C" int reco_tower_create(const reco_tower_desc_t* d, void* stream, reco_
     hipError_t e = hipMalloc(&t->oob, 256);
     if (e == hipSuccess) e = hipMemsetAsync(t->oob, 0, 256, s);
     if (e == hipSuccess && t->mfma) e = hipMalloc(&t->img, IMG_SIZE * sizeof(float));
+    const bool split = t->mfma && d->precision == RECO_PREC_SPLIT_BF16X3;
+    if (e == hipSuccess && split) e = hipMalloc(&t->img_split, tower_split_image_bytes(t->has_l3));
     if (e == hipSuccess && t->mfma && tables) e = hipMalloc(&t->P, (size_t)d->n_users * H1 * sizeof(float));
     if (e == hipSuccess && t->mfma && tables) e = hipMalloc(&t->Q, (size_t)d->n_items * H1 * sizeof(float));
     if (e == hipSuccess) e = hipMemcpyAsync(&t->bp, d->b_predict, sizeof(float), hipMemcpyDeviceToHost, s);
@@ -242,6 +272,8 @@ extern "C" int reco_tower_create(const reco_tower_desc_t* d, void* stream, reco_
     if (t->mfma) {
         rc = tower_pack_image(d->W[1], d->b[1], t->has_l3 ? d->W[2] : nullptr, t->has_l3 ? d->b[2] : nullptr,
                               d->w_predict, t->G, t->has_l3, t->img, s);
+        if (!rc && split)
+            rc = tower_pack_split_image(d->W[1], t->has_l3 ? d->W[2] : nullptr, t->has_l3, t->img, t->img_split, s);
         if (!rc && tables)
             rc = tower_project(t, d->user_mlp, nullptr, 0, d->n_users, d->item_mlp, nullptr, 0, d->n_items, t->P, t->Q, s);
     }
@@ -278,8 +310,7 @@ extern "C" int reco_tower_score_pairs(reco_tower_t* t, const int64_t* user, cons
         return gmf_launch_pairs(d.user_gmf, d.item_gmf, d.w_predict, user, item, d.n_users, d.n_items, B, d.dg, out,
                                 t->bp, d.act, d.lo, d.hi, t->oob, s);
     ProfScope prof(s);
-    return tower_launch_pairs(t->G, t->has_l3, t->img, t->P, t->Q, d.user_gmf, d.item_gmf, user, item, d.n_users,
-                              d.n_items, B, out, t->bp, d.act, d.lo, d.hi, t->oob, s);
+    return run_pairs(t, t->P, t->Q, d.user_gmf, d.item_gmf, user, item, d.n_users, d.n_items, B, out, t->oob, s);
 }
 
 extern "C" size_t reco_tower_rows_workspace_bytes(int64_t B)
@@ -308,8 +339,7 @@ extern "C" int reco_tower_score_rows(reco_tower_t* t, const float* u_gmf, const 
     int rc = tower_project(t, u_mlp, nullptr, 0, B, i_mlp, nullptr, 0, B, P, Q, s);
     if (rc) return rc;
     ProfScope prof(s);
-    return tower_launch_pairs(t->G, t->has_l3, t->img, P, Q, u_gmf, i_gmf, nullptr, nullptr, B, B, B, out, t->bp,
-                              d.act, d.lo, d.hi, nullptr, s);
+    return run_pairs(t, P, Q, u_gmf, i_gmf, nullptr, nullptr, B, B, B, out, nullptr, s);
 }
 
 // ---- matrix / top-k forms ----------------------------------------------------------------------
@@ -330,6 +360,10 @@ static int score_matrix_impl(reco_tower* t, const int64_t* users, int64_t user_b
     int rc = tower_project(t, urows, users, d.n_users, U, d.item_mlp, cands, d.n_items, Qready ? 0 : N, P, Q, s);
     if (rc) return rc;
     ProfScope prof(s);
+    if (t->img_split)
+        return tower_launch_tile_split(t->G, t->has_l3, t->img_split, P, Qready ? Qready : Q, d.user_gmf, d.item_gmf, users,
+                                       cands, user_base, d.n_users, d.n_items, U, N, out, ld_out, t->bp, d.act, d.lo, d.hi,
+                                       t->oob, s);
     return tower_launch_tile(t->G, t->has_l3, t->img, P, Qready ? Qready : Q, d.user_gmf, d.item_gmf, users, cands,
                              user_base, d.n_users, d.n_items, U, N, out, ld_out, t->bp, d.act, d.lo, d.hi, t->oob, s);
 }

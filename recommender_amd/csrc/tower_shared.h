@@ -1,0 +1,229 @@
+// Pieces shared by the two tower translation units (tower.hip: exact fp32 MFMA; tower_split.hip: fp32 operands split
+// into bf16 pieces on the bf16 MFMA): argument blocks, LDS staging of tiles and pair groups, small device helpers.
+#pragma once
+#include "reco_common.h"
+
+namespace {
+
+// ReLU as ONE VALU instruction.  fmaxf() on an MFMA result makes hipcc emit a canonicalising v_max in
+// front of the real one (2 instructions), and beside f32 MFMAs every VALU instruction costs MFMA issue
+// time.  max on the raw bits is exact: negative floats (and -0.0) are negative integers -> +0.0,
+// non-negative floats are unchanged.  (A positive NaN stays NaN, a negative NaN becomes 0.)
+__device__ __forceinline__ float relu1(float v)
+{
+    return __int_as_float(max(__float_as_int(v), 0));
+}
+
+__device__ __forceinline__ f32x4 relu4(f32x4 v)
+{
+    f32x4 r;
+    r.x = relu1(v.x); r.y = relu1(v.y); r.z = relu1(v.z); r.w = relu1(v.w);
+    return r;
+}
+
+__device__ __forceinline__ f32x16 bias16(const float* s_b, int h)
+{
+    // accumulator register r = 4 rq + jj  <-  image [rq][h][jj]
+    f32x16 c;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(s_b + (rq * 2 + h) * 4);
+        c[4 * rq + 0] = v.x; c[4 * rq + 1] = v.y; c[4 * rq + 2] = v.z; c[4 * rq + 3] = v.w;
+    }
+    return c;
+}
+
+__device__ __forceinline__ float dot16_relu(const f32x16 acc, const float* s_w, int h, float part)
+{
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(s_w + (rq * 2 + h) * 4);
+        part = fmaf(w.x, relu1(acc[4 * rq + 0]), part);
+        part = fmaf(w.y, relu1(acc[4 * rq + 1]), part);
+        part = fmaf(w.z, relu1(acc[4 * rq + 2]), part);
+        part = fmaf(w.w, relu1(acc[4 * rq + 3]), part);
+    }
+    return part;
+}
+
+__device__ __forceinline__ float epilogue(float logit, int act, float lo, float hi)
+{
+    if (act == RECO_ACT_RATING) return (1.f / (1.f + __expf(-logit))) * (hi - lo) + lo;
+    return logit;
+}
+
+__device__ __forceinline__ int64_t clamp_id(int64_t id, int64_t n, int32_t* oob)
+{
+    if (id < 0 || id >= n) {
+        if (oob) atomicAdd(oob, 1);
+        return id < 0 ? 0 : n - 1;
+    }
+    return id;
+}
+
+// ---------------------------------------------------------------------------------------------
+// tile kernel: scores for (user chunk) x (item tile); persistent, one 8-wave workgroup per CU
+// ---------------------------------------------------------------------------------------------
+// Each workgroup loads the weight image once and then walks tiles blockIdx.x, blockIdx.x + grid, ...
+// A tile is TUB users x TI items.  The item side of a tile (Q rows, GMF item rows) lives in one of
+// two LDS buffers: while the 8 waves run the MFMAs of tile i out of buffer i & 1, the global loads of
+// tile i + 1 are in flight into registers, are written to the other buffer after the last MFMA and
+// published by the single __syncthreads() per tile.  Wave w owns users w, w + 8, ... of the tile:
+// their P rows (64 VGPRs) stay in registers across the tile's item groups.
+constexpr int TI = 64;         // items per tile (2 MFMA column groups)
+#ifndef RECO_TUB
+#define RECO_TUB 32
+#endif
+constexpr int TUB = RECO_TUB;   // users per tile (4 per wave)
+constexpr int QS = H1 + 4;     // padded LDS row stride of the Q tile: conflict-free ds_read_b128 by 16 rows
+constexpr int TILE_THREADS = 512;
+
+struct TileArgs {
+    const float* img;
+    const float* P;        // [U,128]  row u <-> users[u]
+    const float* Q;        // [N,128]  row n <-> cands[n]
+    const float* EUg;      // GMF user table
+    const float* EIg;      // GMF item table
+    const int64_t* users;  // nullable
+    const int64_t* cands;  // nullable
+    int64_t user_base, n_users, n_items;
+    int64_t U, N;
+    float* out;
+    int64_t ld_out;
+    float bp;
+    int act;
+    float lo, hi;
+    int32_t* oob;
+};
+
+template <int G>
+struct TileStage {
+    static constexpr int NQ = TI * (H1 / 4) / TILE_THREADS;                 // float4 of Q per thread (4)
+    static constexpr int NG = G > 0 ? (TI * (G / 4) + TILE_THREADS - 1) / TILE_THREADS : 0;
+    f32x4 q[NQ];
+    f32x4 g[NG > 0 ? NG : 1];
+};
+
+template <int G>
+__device__ __forceinline__ void tile_stage_load(const TileArgs& a, int64_t n0, bool count_oob, int tid, TileStage<G>& st)
+{
+#pragma unroll
+    for (int s = 0; s < TileStage<G>::NQ; ++s) {
+        const int i = tid + s * TILE_THREADS;
+        const int64_t n = n0 + (i >> 5);
+        st.q[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (n < a.N) st.q[s] = reinterpret_cast<const f32x4*>(a.Q + n * H1)[i & 31];
+    }
+    if constexpr (G > 0) {
+#pragma unroll
+        for (int s = 0; s < TileStage<G>::NG; ++s) {
+            const int i = tid + s * TILE_THREADS;
+            const int r = i / (G / 4), c = i % (G / 4);
+            const int64_t n = n0 + r;
+            st.g[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r < TI && n < a.N) {
+                const int64_t id = clamp_id(a.cands ? a.cands[n] : n, a.n_items, (c == 0 && count_oob) ? a.oob : nullptr);
+                st.g[s] = reinterpret_cast<const f32x4*>(a.EIg + id * G)[c];
+            }
+        }
+    }
+}
+
+template <int G>
+__device__ __forceinline__ void tile_stage_store(float* s_q, float* s_g, int tid, const TileStage<G>& st)
+{
+#pragma unroll
+    for (int s = 0; s < TileStage<G>::NQ; ++s) {
+        const int i = tid + s * TILE_THREADS;
+        *reinterpret_cast<f32x4*>(s_q + (i >> 5) * QS + (i & 31) * 4) = st.q[s];
+    }
+    if constexpr (G > 0) {
+#pragma unroll
+        for (int s = 0; s < TileStage<G>::NG; ++s) {
+            const int i = tid + s * TILE_THREADS;
+            const int r = i / (G / 4), c = i % (G / 4);
+            if (r < TI) *reinterpret_cast<f32x4*>(s_g + r * (G + 4) + c * 4) = st.g[s];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pair kernel: forward(user[B], item[B])
+// ---------------------------------------------------------------------------------------------
+struct PairArgs {
+    const float* img;
+    const float* P;        // [n_users,128]
+    const float* Q;        // [n_items,128]
+    const float* EUg;
+    const float* EIg;
+    const int64_t* user;   // nullable: identity (row b of P / EUg)
+    const int64_t* item;   // nullable: identity
+    int64_t n_users, n_items, B;
+    float* out;
+    float bp;
+    int act;
+    float lo, hi;
+    int32_t* oob;
+};
+
+// Per wave: 32 pairs at a time, fully wave-private (no workgroup barrier in the loop).  The P/Q/GMF rows of the NEXT 32
+// pairs are in flight into registers (two whole 512-B rows per wave instruction) while the MFMAs of the current 32 run
+// out of the wave's LDS staging tile; LDS operations of one wave execute in issue order, so staging writes and operand
+// reads need no barrier between them.
+template <int G>
+struct PairStage {
+    static constexpr int NG = G > 0 ? (32 * (G / 4)) / 64 : 0;   // float4 of each GMF table per lane
+    f32x4 p[16], q[16];
+    f32x4 gu[NG > 0 ? NG : 1], gi[NG > 0 ? NG : 1];
+};
+
+template <int G>
+__device__ __forceinline__ void pair_stage_load(const PairArgs& a, int64_t base, int lane, PairStage<G>& st)
+{
+    const int j = lane & 31, h = lane >> 5;
+    int64_t my_u = 0, my_i = 0;   // ids of the 32 pairs live in lanes 0..31 (mirrored in 32..63)
+    const int64_t b = base + j;
+    if (b < a.B) {
+        my_u = clamp_id(a.user ? a.user[b] : b, a.n_users, h == 0 ? a.oob : nullptr);
+        my_i = clamp_id(a.item ? a.item[b] : b, a.n_items, h == 0 ? a.oob : nullptr);
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int pl = it * 2 + h;
+        const int64_t u = __shfl(my_u, pl);
+        const int64_t i = __shfl(my_i, pl);
+        st.p[it] = reinterpret_cast<const f32x4*>(a.P + u * H1)[j];
+        st.q[it] = reinterpret_cast<const f32x4*>(a.Q + i * H1)[j];
+    }
+    if constexpr (G > 0) {
+        constexpr int C = G / 4;
+#pragma unroll
+        for (int it = 0; it < PairStage<G>::NG; ++it) {
+            const int e = it * 64 + lane;
+            const int pl = e / C, c = e % C;
+            const int64_t u = __shfl(my_u, pl);
+            const int64_t i = __shfl(my_i, pl);
+            st.gu[it] = reinterpret_cast<const f32x4*>(a.EUg + u * G)[c];
+            st.gi[it] = reinterpret_cast<const f32x4*>(a.EIg + i * G)[c];
+        }
+    }
+}
+
+template <int G>
+__device__ __forceinline__ void pair_stage_store(float* s_x, float* s_gp, int lane, const PairStage<G>& st)
+{
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int it = 0; it < 16; ++it)
+        *reinterpret_cast<f32x4*>(s_x + (it * 2 + h) * QS + 4 * j) = relu4(st.p[it] + st.q[it]);
+    if constexpr (G > 0) {
+        constexpr int C = G / 4;
+#pragma unroll
+        for (int it = 0; it < PairStage<G>::NG; ++it) {
+            const int e = it * 64 + lane;
+            *reinterpret_cast<f32x4*>(s_gp + (e / C) * (G + 4) + 4 * (e % C)) = st.gu[it] * st.gi[it];
+        }
+    }
+}
+
+}  // namespace

@@ -109,7 +109,7 @@ class NCF(nn.Module):
     def _tower(self, device):
         own = self._own_tensors()
         flat = [own[k] for k in own if k != "layers"] + [x for pair in own.get("layers", []) for x in pair]
-        sig = (str(device), self._rating_epilogue()) + tuple((p.data_ptr(), p._version, str(p.device)) for p in flat)
+        sig = (str(device), self._rating_epilogue(), ops.tower_precision()) + tuple((p.data_ptr(), p._version, str(p.device)) for p in flat)
         hit = _cache.get(self)
         if hit is not None and hit[0] == sig:
             return hit[1]

@@ -105,7 +105,7 @@ class NCF(nn.Module):
     def _tower(self, device):
         linears = [m for m in self.mlp if isinstance(m, nn.Linear)]
         ps = [p for lin in linears for p in (lin.weight, lin.bias)] + [self.output.weight, self.output.bias]
-        sig = (str(device), bool(self.rating_output), float(self.rating_min), float(self.rating_max)) + tuple(
+        sig = (str(device), bool(self.rating_output), float(self.rating_min), float(self.rating_max), ops.tower_precision()) + tuple(
             (p.data_ptr(), p._version, str(p.device)) for p in ps)
         hit = _tower_cache.get(self)
         if hit is not None and hit[0] == sig:

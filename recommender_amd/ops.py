@@ -4,6 +4,7 @@ Everything here runs on the GPU through libreco_hip.so; there is no eager-PyTorc
 product path.  torch is used for allocation (torch.empty), streams and device guards only.
 """
 import ctypes
+import os
 
 import torch
 
@@ -197,12 +198,35 @@ def _mask(m, like):
 # ----------------------------------------------------------------------------------------------
 # K-b tower handle
 # ----------------------------------------------------------------------------------------------
+PRECISIONS = {"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_SPLIT_BF16X3}
+_default_precision = [os.environ.get("RECO_TOWER_PRECISION", "f32")]
+
+
+def set_tower_precision(mode):
+    """How the MFMA layers of the fused tower multiply (include/reco_hip.h, RECO_PREC_*): "f32" (exact fp32 MFMA, the
+    default) or "bf16x3" (fp32 operands split exactly into three bf16 pieces, six cross terms on the bf16 MFMA, fp32
+    accumulate; same parity gates, ~1.7x the throughput).  Applies to towers built afterwards; returns the old mode."""
+    if mode not in PRECISIONS:
+        raise ValueError("precision must be one of %s, got %r" % (sorted(PRECISIONS), mode))
+    old = _default_precision[0]
+    _default_precision[0] = mode
+    return old
+
+
+def tower_precision():
+    mode = _default_precision[0]
+    if mode not in PRECISIONS:
+        raise ValueError("RECO_TOWER_PRECISION must be one of %s, got %r" % (sorted(PRECISIONS), mode))
+    return mode
+
+
 class Tower:
     """Owns a reco_tower_t.  Keeps the weight tensors alive (the handle borrows their memory)."""
 
     def __init__(self, *, user_gmf=None, item_gmf=None, user_mlp=None, item_mlp=None, layers=(), w_predict, b_predict,
-                 dg=None, dm=None, act=None, lo=1.0, hi=5.0):
+                 dg=None, dm=None, act=None, lo=1.0, hi=5.0, precision=None):
         require_gpu()
+        self.precision = precision or tower_precision()
         dev = w_predict.device
         self.device = dev
         keep = []
@@ -236,6 +260,7 @@ class Tower:
         wp = f(w_predict.reshape(-1), "w_predict", 1); bp = f(b_predict.reshape(-1), "b_predict", 1)
         d.w_predict = wp.data_ptr(); d.b_predict = bp.data_ptr()
         d.act = ACTS[act]; d.lo = lo; d.hi = hi
+        d.precision = PRECISIONS[self.precision]
         self.n_users, self.n_items = int(d.n_users), int(d.n_items)
         self._keep = keep
         self._h = ctypes.c_void_p()

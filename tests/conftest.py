@@ -78,3 +78,12 @@ def g2b():
 @pytest.fixture(scope="session")
 def g6():
     return load_golden("g6_files.npz")
+
+
+@pytest.fixture(params=["f32", "bf16x3"])
+def tower_precision(request):
+    """Runs a tower test once per multiply mode of the MFMA layers (include/reco_hip.h RECO_PREC_*), same gates for both."""
+    from recommender_amd import ops
+    old = ops.set_tower_precision(request.param)
+    yield request.param
+    ops.set_tower_precision(old)

@@ -25,7 +25,7 @@ def _neumf(n_users, n_items, seed=0, name="NeuMF-end"):
     return m.cuda(), sd
 
 
-def test_cfg2_full_catalog_scoring_and_top10():
+def test_cfg2_full_catalog_scoring_and_top10(tower_precision):
     m, sd = _neumf(6038, 3533)
     S = m.score_matrix()                                   # 21,332,254 pairs
     assert S.shape == (6038, 3533)
@@ -59,7 +59,7 @@ def test_cfg2_full_catalog_scoring_and_top10():
     assert torch.equal(a, ids[ul]) and torch.equal(b, vals[ul])
 
 
-def test_cfg1_full_protocol_size_pair_list():
+def test_cfg1_full_protocol_size_pair_list(tower_precision):
     """115,056 test cases x 100 candidates = 11,505,600 pairs through forward(user, item)."""
     from recommender_amd import ops
     from recommender_amd.helpers.ranking_metrics import hit_ndcg_batch
@@ -120,7 +120,7 @@ def test_cfg3_autorec_full_reconstruction_and_masked_topk():
     assert np.array_equal(ids.cpu().numpy(), oid)                  # clamp plateaus: ties resolved by ascending item id
 
 
-def test_cfg4_hybrid_full_catalog():
+def test_cfg4_hybrid_full_catalog(tower_precision):
     from recommender_amd.hybridautorecncf.model import HybridAutoRecNCF
     torch.manual_seed(0)
     m = HybridAutoRecNCF(6040, 3706, 64, [128, 64], rating_output=False).eval()
@@ -144,7 +144,7 @@ def test_cfg4_hybrid_full_catalog():
     assert np.array_equal(ids.cpu().numpy(), oid) and np.array_equal(vals.cpu().numpy(), oval)
 
 
-def test_cfg5_slice_million_item_catalog_top100_user_chunking():
+def test_cfg5_slice_million_item_catalog_top100_user_chunking(tower_precision):
     """Synthetic-scale slice: 96 users x 1,000,000 items, top-100; exercises user chunking and multi-wave row splits."""
     m, sd = _neumf(4096, 1_000_000, seed=5)
     users = torch.arange(1000, 1096, device="cuda")

@@ -45,7 +45,7 @@ def test_g1_real_gmf_protocol(g1):
 
 
 @pytest.mark.parametrize("tag", ["end", "pre", "gmf", "mlp"])
-def test_g2_small_models_pairs_matrix_topk(g2, tag):
+def test_g2_small_models_pairs_matrix_topk(g2, tag, tower_precision):
     sd = golden_sd(g2, tag)
     m = _ncf_from_sd(sd)
     ref32 = g2[tag + "__scores"]; ref64 = g2[tag + "__scores64"]
@@ -96,7 +96,7 @@ def test_g2b_other_tower_shapes_run_on_the_unfused_hip_path(g2b, tag):
         m(torch.tensor([U]).cuda(), torch.tensor([0]).cuda())
 
 
-def test_g2_subset_users_and_candidates(g2):
+def test_g2_subset_users_and_candidates(g2, tower_precision):
     sd = golden_sd(g2, "end")
     m = _ncf_from_sd(sd)
     ref = g2["end__scores"]
@@ -137,7 +137,7 @@ def test_weight_update_invalidates_packed_cache(g2):
     assert abs(m(u, i).item() - (a + 1.0)) < 1e-5
 
 
-def test_g2r_rating_variants(g2r):
+def test_g2r_rating_variants(g2r, tower_precision):
     from recommender_amd.ncf.rating_model import NCFRating
     for tag in ("neumf", "gmfreal"):
         sd = golden_sd(g2r, tag)
@@ -189,7 +189,7 @@ def test_g3_tie_storm(g3):
     assert np.array_equal(ids.cpu().numpy(), g3["tie__api_top100"])
 
 
-def test_g4_hybrid(g4):
+def test_g4_hybrid(g4, tower_precision):
     from recommender_amd.hybridautorecncf.model import HybridAutoRecNCF
     for tag, rating, (U, I), hd in (("rating", True, (83, 47), (48, 40)), ("logit", False, (40, 26), (256, 128))):
         sd = golden_sd(g4, tag)

@@ -110,6 +110,15 @@ def bench_tower():
     ms = timeit(lambda: t.score_matrix(None, None, check_ids=False, out=out))
     emit("tower_tile_kernel<32,true> (+projections)", "6038 x 3533", ms, "mfma", 6038 * 3533 * 86176, "86,176 FLOP/pair algorithmic",
          "pairs/s = %.3g" % (6038 * 3533 / ms * 1e3))
+    ops.set_tower_precision("bf16x3")
+    ts = m._tower(dev)
+    ms = timeit(lambda: ts.score_pairs(u, i, check_ids=False))
+    emit("tower_pairs_split_kernel<32,true> (bf16x3)", "B=%d (115,056 cases x 100)" % B, ms, "mfma", B * 86176,
+         "86,176 FLOP/pair algorithmic", "pairs/s = %.3g" % (B / ms * 1e3))
+    ms = timeit(lambda: ts.score_matrix(None, None, check_ids=False, out=out))
+    emit("tower_tile_split_kernel<32,true> (bf16x3, +projections)", "6038 x 3533", ms, "mfma", 6038 * 3533 * 86176,
+         "86,176 FLOP/pair algorithmic", "pairs/s = %.3g" % (6038 * 3533 / ms * 1e3))
+    ops.set_tower_precision("f32")
     from recommender_amd.hybridautorecncf.model import HybridAutoRecNCF
     h = HybridAutoRecNCF(6040, 3706, 64, [128, 64], rating_output=False).eval().to(dev)
     R = (torch.rand(6040, 3706, device=dev) < 0.045).float()
@@ -120,6 +129,11 @@ def bench_tower():
     tw = h.ncf.score_matrix(zu, zi)
     ms = timeit(lambda: tw.score_matrix(None, None, check_ids=False), reps=10)
     emit("tower_tile_kernel<64,false> (+projections)", "6040 x 3706", ms, "mfma", 6040 * 3706 * 49472, "49,472 FLOP/pair algorithmic")
+    ops.set_tower_precision("bf16x3")
+    tws = h.ncf.score_matrix(zu, zi)
+    ms = timeit(lambda: tws.score_matrix(None, None, check_ids=False), reps=10)
+    emit("tower_tile_split_kernel<64,false> (bf16x3, +projections)", "6040 x 3706", ms, "mfma", 6040 * 3706 * 49472, "49,472 FLOP/pair algorithmic")
+    ops.set_tower_precision("f32")
 
 
 if __name__ == "__main__":
