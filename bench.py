@@ -103,16 +103,13 @@ def main():
     from recommender_amd import _lib
     from recommender_amd.dist import sharded_score_topk, shard_range
 
+    from recommender_amd import ops
+
     total_users = N_USERS * world
     model = build_model(total_users, device)
-    tower = model._tower(device)
     start, count = shard_range(total_users, rank, world)
     assert count == N_USERS
-    ws = tower.topk_workspace(count, N_ITEMS, K)
-    out = (torch.empty((count, K), dtype=torch.int32, device=device), torch.empty((count, K), dtype=torch.float32, device=device))
-
-    def step():
-        return sharded_score_topk(model, K, total_users, ws=ws, out=out)
+    L = _lib.lib()
 
     def fence():
         torch.cuda.synchronize(device)
@@ -120,26 +117,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        ids, vals = step()
-    L = _lib.lib()
-    _lib.check(L.reco_profile_enable(args.steps + 4))
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ids, vals = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    ms = (ctypes.c_float * (args.steps + 4))()
-    n = ctypes.c_int(0)
-    _lib.check(L.reco_profile_collect(ms, args.steps + 4, ctypes.byref(n)))
-    _lib.check(L.reco_profile_enable(0))
-    tile_ms = float(np.mean(list(ms)[: n.value])) if n.value else float("nan")
+    def timed_run(precision):
+        """W warm-up steps, then K timed steps between fences; (seconds max over ranks, mean ms of the tile kernel, ids, vals)."""
+        ops.set_tower_precision(precision)
+        tower = model._tower(device)
+        ws = tower.topk_workspace(count, N_ITEMS, K)
+        out = (torch.empty((count, K), dtype=torch.int32, device=device), torch.empty((count, K), dtype=torch.float32, device=device))
+        for _ in range(args.warmup):
+            ids, vals = sharded_score_topk(model, K, total_users, ws=ws, out=out)
+        _lib.check(L.reco_profile_enable(args.steps + 4))
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ids, vals = sharded_score_topk(model, K, total_users, ws=ws, out=out)
+        fence()
+        el = time.perf_counter() - t0
+        ms = (ctypes.c_float * (args.steps + 4))()
+        n = ctypes.c_int(0)
+        _lib.check(L.reco_profile_collect(ms, args.steps + 4, ctypes.byref(n)))
+        _lib.check(L.reco_profile_enable(0))
+        kernel_ms = float(np.mean(list(ms)[: n.value])) if n.value else float("nan")
+        t = torch.tensor([el], dtype=torch.float64, device=device)
+        if launched:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), kernel_ms, n.value, ids.clone(), vals.clone()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if launched:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    # the headline: exact fp32 MFMA (every product the exact fp32 product)
+    elapsed, tile_ms, n_timed, ids, vals = timed_run("f32")
+    # the same job in the opt-in split-operand mode (fp32 = 3 bf16 pieces on the bf16 MFMA, fp32 accumulate)
+    s_elapsed, s_tile_ms, _, s_ids, s_vals = timed_run("bf16x3")
+    ops.set_tower_precision("f32")
 
     if rank == 0:
         pairs_per_rank = N_USERS * N_ITEMS
@@ -160,11 +167,19 @@ def main():
                          "traffic": measured_traffic("tower_tile_kernel<32, true>") if world == 1 else None,
                          "traffic_note": "HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/*_hbm_traffic.json), not live; "
                                          "algorithmic output is 85.3 MB per launch",
-                         "kernel_ms": tile_ms, "launches_timed": n.value, "flop_per_pair_algorithmic": FLOP_PER_PAIR,
+                         "kernel_ms": tile_ms, "launches_timed": n_timed, "flop_per_pair_algorithmic": FLOP_PER_PAIR,
                          "executed": {"flop_per_pair": FLOP_PER_PAIR_EXEC, "achieved": executed, "frac": executed / PEAK_F32_MFMA_TFLOPS,
                                       "note": "layer 1 is factorised (W1[u;i] = W1u u + W1i i): frac above counts the reference's "
                                               "86,176 FLOP/pair, this one the FLOPs the kernel issues; MFMA utilisation is the executed figure"}},
         }
+        dev = (s_vals - vals).abs() / vals.abs().clamp_min(1e-30)
+        res["split_bf16x3"] = {
+            "value": pairs / s_elapsed, "unit": "pairs/s", "ms_per_step": s_elapsed / args.steps * 1e3,
+            "kernel": "tower_tile_split_kernel<32,true>", "kernel_ms": s_tile_ms, "speedup_vs_f32": elapsed / s_elapsed,
+            "top%d_ids_equal_to_f32" % K: float((s_ids == ids).double().mean().item()),
+            "top%d_scores_max_rel_dev_vs_f32" % K: float(dev.max().item()),
+            "note": "opt-in RECO_PREC_SPLIT_BF16X3 (not the headline): fp32 operands split exactly into three bf16 pieces, six cross "
+                    "terms on v_mfma_f32_32x32x16_bf16, fp32 accumulate; passes the same parity tests as the exact mode"}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(model, ids.cpu().numpy(), vals.cpu().numpy())
         print(json.dumps(res), flush=True)

@@ -165,3 +165,26 @@ def test_cfg5_slice_million_item_catalog_top100_user_chunking(tower_precision):
     # property: every returned list is sorted descending and ids are unique
     v = vals.cpu().numpy(); i = ids.cpu().numpy()
     assert (np.diff(v, axis=1) <= 0).all() and all(len(set(row)) == 100 for row in i)
+
+
+def test_split_mode_deviation_is_at_fp32_rounding_level():
+    """RECO_PREC_SPLIT_BF16X3 against the fp64 oracle at cfg2 size: its error is of the size of the exact-fp32 kernel's own
+    rounding error (both are fp32-accumulated dot products; the split drops only terms below 2^-24 relative)."""
+    from recommender_amd import ops
+    m, sd = _neumf(6038, 3533)
+    rng = np.random.default_rng(5)
+    users = np.sort(rng.choice(6038, 64, replace=False))
+    ref64 = O.ncf_score_all(sd, users, np.float64)
+    ut = torch.from_numpy(users).cuda()
+    err = {}
+    for mode in ("f32", "bf16x3"):
+        old = ops.set_tower_precision(mode)
+        try:
+            got = m.score_matrix(ut).cpu().numpy().astype(np.float64)
+        finally:
+            ops.set_tower_precision(old)
+        err[mode] = np.abs(got - ref64).max()
+    scale = np.abs(ref64).max()
+    print("max |score| %.3f; max abs deviation from fp64: exact fp32 MFMA %.3e, split bf16x3 %.3e" % (scale, err["f32"], err["bf16x3"]))
+    assert err["f32"] <= 1e-6 * max(scale, 1.0)
+    assert err["bf16x3"] <= 2.0 * err["f32"] + 1e-7 * max(scale, 1.0)
