@@ -16,13 +16,16 @@
 // Cost per 32 pairs and wave: 96 + 24 bf16 MFMAs (32 cycles each) instead of 128 + 32 fp32 MFMAs (64 cycles each),
 // plus ~11 VALU instructions per pair of elements for the splitting of the activations (weights are split once, when
 // the image is packed).  The splitting of k-step s+1 is interleaved, 5 instructions per MFMA, with the MFMAs of
-// k-step s: an MFMA holds the SIMD's issue port for 8 of its 32 cycles, the rest is free for VALU.
+// k-step s: an MFMA holds the SIMD's issue port for 8 of its 32 cycles, the rest is free for VALU.  Measured
+// (tools/split_probe.hip): the chip runs this instruction mix at 1.74-1.89 GHz (power), 44-48 cycles per MFMA slot.
 //
 // Operand maps (v_mfma_f32_32x32x16_bf16): lane l = (r = l & 31, h = l >> 5) holds A[row r][k = 8h + e] and
 // B[k = 8h + e][col r], e = 0..7; D as in tower.hip.  k-step s of layer 2 carries features 16 s + 8 h + e; k-step
 // s' = 2 t + g of layer 3 carries the features held by registers 8 g .. 8 g + 7 of layer 2's accumulator t, so the
 // accumulators are layer 3's B operand without any lane movement, exactly as in the exact kernel.
 #include "tower_shared.h"
+
+#include <type_traits>
 
 namespace {
 
@@ -97,27 +100,10 @@ __global__ void pack_split_kernel(PackSplitArgs a, unsigned char* __restrict__ o
 // ---------------------------------------------------------------------------------------------
 struct Frag3 { bf16x8 hi, mid, lo; };
 struct Build { u32x4 H, M, L; };
-struct Pair3 { float xa, xb, ra, rb; };          // one element pair on its way through the three chunks
 
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
 
-// the splitting of one element pair, in three chunks of 5 VALU instructions or fewer
-__device__ __forceinline__ void chunk0(Build& bd, Pair3& st, int pr, float a, float b)
-{
-    st.xa = a; st.xb = b;
-    bd.H[pr] = pk_bf16(a, b);
-}
-__device__ __forceinline__ void chunk1(Build& bd, Pair3& st, int pr)
-{
-    st.ra = st.xa - lo_f(bd.H[pr]); st.rb = st.xb - hi_f(bd.H[pr]);
-    bd.M[pr] = pk_bf16(st.ra, st.rb);
-}
-__device__ __forceinline__ void chunk2(Build& bd, Pair3& st, int pr)
-{
-    const float sa = st.ra - lo_f(bd.M[pr]), sb = st.rb - hi_f(bd.M[pr]);
-    bd.L[pr] = pk_bf16(sa, sb);
-}
 __device__ __forceinline__ Frag3 finish(const Build& bd)
 {
     Frag3 f;
@@ -125,6 +111,24 @@ __device__ __forceinline__ Frag3 finish(const Build& bd)
     return f;
 }
 
+// The same splitting as nine micro-op groups, so that a slot can mix groups of two different element pairs: a slot's
+// instructions are then mostly independent of each other instead of one three-deep dependent chain .
+struct Pair9 { float xa, xb, ta, tb; };
+template <bool RELU>
+__device__ __forceinline__ void mop(Build& bd, Pair9& st, int pr, int m, float pre_a, float pre_b)
+{
+    switch (m) {
+    case 0: st.xa = pre_a; st.xb = pre_b; break;                                   // (the provider's add, if any)
+    case 1: if (RELU) { st.xa = relu1(st.xa); st.xb = relu1(st.xb); } break;
+    case 2: bd.H[pr] = pk_bf16(st.xa, st.xb); break;
+    case 3: st.ta = lo_f(bd.H[pr]); st.tb = hi_f(bd.H[pr]); break;
+    case 4: st.xa -= st.ta; st.xb -= st.tb; break;
+    case 5: bd.M[pr] = pk_bf16(st.xa, st.xb); break;
+    case 6: st.ta = lo_f(bd.M[pr]); st.tb = hi_f(bd.M[pr]); break;
+    case 7: st.xa -= st.ta; st.xb -= st.tb; break;
+    default: bd.L[pr] = pk_bf16(st.xa, st.xb); break;
+    }
+}
 struct W6 { bf16x8 h0, m0, l0, h1, m1, l1; };
 __device__ __forceinline__ W6 load_w2(const bf16x8* s_w, int s, int lane)
 {
@@ -155,8 +159,13 @@ __device__ __forceinline__ f32x16 term(int t, const bf16x8& wh, const bf16x8& wm
 struct X8 { f32x4 a, b; };
 
 // Layers 2 (+3) and the MLP half of the predict layer for the 32 pairs of this wave.
-// x1.raw(s) issues the LDS reads of this lane's 8 layer-1 inputs [16 s + 8 h .. + 7] of its pair and
-// x1.elem(s, raw, e) turns element e into the activation relu(P + Q) (identity when the staged tile holds activations).
+// x1.raw(s) issues the LDS reads of this lane's 8 layer-1 inputs [16 s + 8 h .. + 7] of its pair, x1.pre(s, raw, e) is
+// element e before the ReLU (P + Q), X1::RELU says whether the ReLU is still to be applied (false when the staged tile
+// already holds activations).
+//
+// Schedule: the MFMAs of k-step s run beside the splitting of k-step s + 1's operands.  A "slot" is one MFMA plus the
+// VALU groups listed by slot6(): two element pairs advance together, so the instructions of a slot are mostly
+// independent of each other; six slots take two pairs through all nine groups.
 template <bool L3, typename X1>
 __device__ __forceinline__ float split_mlp_part(const bf16x8* s_w, const float* s_tail, int lane, X1 x1)
 {
@@ -165,33 +174,46 @@ __device__ __forceinline__ float split_mlp_part(const bf16x8* s_w, const float* 
     f32x16 acc1 = bias16(s_tail + TAIL_B2 + 32, h);
 
     Build bd;
-    Pair3 st[4];
+    Pair9 st[4];
+    // slot k (0..5) for the element pairs A, B:   k even: g(A) g(B) g'(A)    k odd: g(B) g'(A) g'(B)
+    auto slot6 = [&](auto relu_tag, int k, int A, int B, auto pre) {
+        constexpr bool R = decltype(relu_tag)::value;
+        constexpr int g0[6] = {0, 1, 3, 4, 6, 7}, g1[6] = {0, 2, 3, 5, 6, 8}, g2[6] = {1, 2, 4, 5, 7, 8};
+        if ((k & 1) == 0) {
+            mop<R>(bd, st[A], A, g0[k], pre(A, 0), pre(A, 1));
+            mop<R>(bd, st[B], B, g1[k], pre(B, 0), pre(B, 1));
+            mop<R>(bd, st[A], A, g2[k], 0.f, 0.f);
+        } else {
+            mop<R>(bd, st[B], B, g0[k], 0.f, 0.f);
+            mop<R>(bd, st[A], A, g1[k], 0.f, 0.f);
+            mop<R>(bd, st[B], B, g2[k], 0.f, 0.f);
+        }
+    };
+    using relu_x1 = std::integral_constant<bool, X1::RELU != 0>;
+    using relu_yes = std::integral_constant<bool, true>;
+
     X8 q = x1.raw(0);
+    {
+        auto pre0 = [&](int pr, int w) { return x1.pre(0, q, 2 * pr + w); };
 #pragma unroll
-    for (int pr = 0; pr < 4; ++pr) {      // k-step 0's operands: nothing to hide them behind
-        chunk0(bd, st[pr], pr, x1.elem(0, q, 2 * pr), x1.elem(0, q, 2 * pr + 1));
-        chunk1(bd, st[pr], pr);
-        chunk2(bd, st[pr], pr);
+        for (int k = 0; k < 6; ++k) { slot6(relu_x1{}, k, 0, 1, pre0); slot6(relu_x1{}, k, 2, 3, pre0); }   // k-step 0: nothing to hide behind
     }
     Frag3 f = finish(bd);
     W6 w = load_w2(s_w, 0, lane);
     q = x1.raw(1);
     FENCE();
-    // k-steps 0..6: slot i = MFMA (accumulator i & 1, term i >> 1) + chunk (i % 3) of element pair (i / 3) of k-step s + 1
 #pragma unroll
     for (int s = 0; s < 7; ++s) {
         const W6 wn = load_w2(s_w, s + 1, lane);
         X8 qn = q;
         if (s + 2 < 8) qn = x1.raw(s + 2);
         FENCE();
+        auto pre = [&](int pr, int wh) { return x1.pre(s + 1, q, 2 * pr + wh); };
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
+        for (int i = 0; i < 12; ++i) {       // slot i: MFMA (accumulator i & 1, term i >> 1)
             if (i & 1) acc1 = term(i >> 1, w.h1, w.m1, w.l1, f, acc1);
             else acc0 = term(i >> 1, w.h0, w.m0, w.l0, f, acc0);
-            const int pr = i / 3, c = i % 3;
-            if (c == 0) chunk0(bd, st[pr], pr, x1.elem(s + 1, q, 2 * pr), x1.elem(s + 1, q, 2 * pr + 1));
-            else if (c == 1) chunk1(bd, st[pr], pr);
-            else chunk2(bd, st[pr], pr);
+            slot6(relu_x1{}, i % 6, 2 * (i / 6), 2 * (i / 6) + 1, pre);
             FENCE();
         }
         f = finish(bd); w = wn; q = qn;
@@ -203,17 +225,15 @@ __device__ __forceinline__ float split_mlp_part(const bf16x8* s_w, const float* 
         FENCE();
 #pragma unroll
         for (int i = 0; i < 6; ++i) { acc0 = term(i, w.h0, w.m0, w.l0, f, acc0); FENCE(); }
+        {
+            auto pre = [&](int pr, int wh) { return acc0[2 * pr + wh]; };
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            acc1 = term(i, w.h1, w.m1, w.l1, f, acc1);
-#pragma unroll
-            for (int cc = 2 * i; cc < 2 * i + 2; ++cc) {
-                const int pr = cc / 3, c = cc % 3;
-                if (c == 0) chunk0(bd, st[pr], pr, relu1(acc0[2 * pr]), relu1(acc0[2 * pr + 1]));
-                else if (c == 1) chunk1(bd, st[pr], pr);
-                else chunk2(bd, st[pr], pr);
+            for (int i = 0; i < 6; ++i) {
+                acc1 = term(i, w.h1, w.m1, w.l1, f, acc1);
+                slot6(relu_yes{}, i, 0, 1, pre);
+                slot6(relu_yes{}, i, 2, 3, pre);
+                FENCE();
             }
-            FENCE();
         }
         f = finish(bd);
         f32x16 acc3 = bias16(s_tail + TAIL_B3, h);
@@ -222,18 +242,14 @@ __device__ __forceinline__ float split_mlp_part(const bf16x8* s_w, const float* 
             W3r wn3 = w3;
             if (s3 + 1 < 4) wn3 = load_w3(s_w, s3 + 1, lane);
             FENCE();
+            auto pre = [&](int pr, int wh) {
+                const int r = 8 * ((s3 + 1) & 1) + 2 * pr + wh;
+                return s3 + 1 < 2 ? acc0[r] : acc1[r];
+            };
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 acc3 = term(i, w3.h, w3.m, w3.l, f, acc3);
-                if (s3 + 1 < 4) {
-#pragma unroll
-                    for (int cc = 2 * i; cc < 2 * i + 2; ++cc) {
-                        const int pr = cc / 3, c = cc % 3, r = 8 * ((s3 + 1) & 1) + 2 * pr;
-                        if (c == 0) chunk0(bd, st[pr], pr, relu1(s3 + 1 < 2 ? acc0[r] : acc1[r]), relu1(s3 + 1 < 2 ? acc0[r + 1] : acc1[r + 1]));
-                        else if (c == 1) chunk1(bd, st[pr], pr);
-                        else chunk2(bd, st[pr], pr);
-                    }
-                }
+                if (s3 + 1 < 4) { slot6(relu_yes{}, i, 0, 1, pre); slot6(relu_yes{}, i, 2, 3, pre); }
                 FENCE();
             }
             if (s3 + 1 < 4) f = finish(bd);
@@ -325,9 +341,10 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tower_tile_split_kernel(TileA
                     {
                         return X8{*reinterpret_cast<const f32x4*>(qrow + 16 * s), *reinterpret_cast<const f32x4*>(qrow + 16 * s + 4)};
                     }
-                    __device__ __forceinline__ float elem(int s, const X8& q, int e) const
+                    enum { RELU = 1 };
+                    __device__ __forceinline__ float pre(int s, const X8& q, int e) const
                     {
-                        return relu1((e < 4 ? p[2 * s][e] : p[2 * s + 1][e - 4]) + x8_get(q, e));
+                        return (e < 4 ? p[2 * s][e] : p[2 * s + 1][e - 4]) + x8_get(q, e);
                     }
                 };
                 float part = split_mlp_part<L3>(s_w, s_tail, lane, X1Tile{qrow, p});
@@ -396,7 +413,8 @@ __global__ __launch_bounds__(256, 1) void tower_pairs_split_kernel(PairArgs a)
             {
                 return X8{*reinterpret_cast<const f32x4*>(xrow + 16 * s), *reinterpret_cast<const f32x4*>(xrow + 16 * s + 4)};
             }
-            __device__ __forceinline__ float elem(int, const X8& q, int e) const { return x8_get(q, e); }
+            enum { RELU = 0 };                          // the staged tile holds relu(P + Q)
+            __device__ __forceinline__ float pre(int, const X8& q, int e) const { return x8_get(q, e); }
         };
         float part = split_mlp_part<L3>(s_w, s_tail, lane, X1Pair{xrow});
         if constexpr (G > 0) {
