@@ -24,19 +24,16 @@ from recommender_amd.dist import all_gather_topk
 U_TOTAL, N_ITEMS, K = 10_000_000, 1_000_000, 100
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--users-per-gpu", type=int, default=1024)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    args = ap.parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
-    if launched:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+def run(dev, world, rank, launched, users_per_gpu=1024, steps=3, warmup=1, precision="f32"):
+    """Times `steps` cfg5 steps on this rank's slice; returns the result dict on rank 0 (None elsewhere)."""
+    old = ops.set_tower_precision(precision)
+    try:
+        return _run(dev, world, rank, launched, users_per_gpu, steps, warmup, precision)
+    finally:
+        ops.set_tower_precision(old)
+
+
+def _run(dev, world, rank, launched, upg, steps, warmup, precision):
     g = torch.Generator(device=dev).manual_seed(5)
 
     def table(rows, dim):                       # N(0, 0.01^2) as ncf_model.py:134-140, x25 so scores are O(1)
@@ -48,7 +45,6 @@ def main():
     layers = [(l.weight.detach().to(dev), l.bias.detach().to(dev)) for l in small.MLP_layers if isinstance(l, torch.nn.Linear)]
     tower = ops.Tower(user_gmf=table(U_TOTAL, 32), item_gmf=table(N_ITEMS, 32), user_mlp=table(U_TOTAL, 128), item_mlp=table(N_ITEMS, 128),
                       layers=layers, w_predict=small.predict_layer.weight.detach().to(dev), b_predict=small.predict_layer.bias.detach().to(dev))
-    upg = args.users_per_gpu
     ws = tower.topk_workspace(upg, N_ITEMS, K)
     out = (torch.empty((upg, K), dtype=torch.int32, device=dev), torch.empty((upg, K), dtype=torch.float32, device=dev))
 
@@ -63,26 +59,48 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
+    for i in range(steps):
+        step(warmup + i)
     fence()
     el = time.perf_counter() - t0
     t = torch.tensor([el], dtype=torch.float64, device=dev)
     if launched:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t.item())
+    resident = torch.cuda.memory_allocated(dev) / 1e9
+    del tower, ws, out
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    users = upg * world * steps
+    return {"metric": "full-catalog top-100 users/s (synthetic NeuMF 10M users x 1M items)", "value": users / el, "unit": "users/s",
+            "pairs_per_s": users * N_ITEMS / el, "n_gpus": world, "steps": steps, "ms_per_step": el / steps * 1e3,
+            "users_per_gpu_per_step": upg, "scaling": "weak", "dtype": "f32", "precision": precision,
+            "data": "synthetic (on-device N(0,0.01)x25 tables, seed 5)",
+            "full_job_extrapolated_s": U_TOTAL / (users / el), "hbm_resident_GB": resident}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--users-per-gpu", type=int, default=1024)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--precision", default="f32", choices=sorted(ops.PRECISIONS))
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if launched:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    res = run(dev, world, rank, launched, args.users_per_gpu, args.steps, args.warmup, args.precision)
     if rank == 0:
-        users = upg * world * args.steps
-        print(json.dumps({
-            "metric": "full-catalog top-100 users/s (synthetic NeuMF 10M users x 1M items)", "value": users / el, "unit": "users/s",
-            "pairs_per_s": users * N_ITEMS / el, "n_gpus": world, "steps": args.steps, "ms_per_step": el / args.steps * 1e3,
-            "users_per_gpu_per_step": upg, "scaling": "weak", "dtype": "f32", "data": "synthetic (on-device N(0,0.01)x25 tables, seed 5)",
-            "full_job_extrapolated_s": U_TOTAL / (users / el),
-            "hbm_resident_GB": torch.cuda.memory_allocated(dev) / 1e9}), flush=True)
+        print(json.dumps(res), flush=True)
     if launched:
         dist.destroy_process_group()
 
