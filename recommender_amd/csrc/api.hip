@@ -59,12 +59,15 @@ extern "C" int reco_abi_version(void) { return 2; }
 // ---------------------------------------------------------------------------------------------
 // measurement hook: hipEvent pairs around the dominant kernel's launches
 // ---------------------------------------------------------------------------------------------
+#include <mutex>
 #include <vector>
+static std::mutex g_prof_mu;                 // the hook is process-wide; scoring calls may come from several threads
 static std::vector<hipEvent_t> g_prof_ev;   // 2 per launch
 static int g_prof_used = 0;
 
 extern "C" int reco_profile_enable(int max_launches)
 {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     for (hipEvent_t e : g_prof_ev) (void)hipEventDestroy(e);
     g_prof_ev.clear();
     g_prof_used = 0;
@@ -79,6 +82,7 @@ extern "C" int reco_profile_enable(int max_launches)
 extern "C" int reco_profile_collect(float* ms_out, int capacity, int* n_out)
 {
     RECO_REQUIRE(ms_out && n_out, "profile_collect: null pointer");
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     int n = 0;
     for (int i = 0; i < g_prof_used && n < capacity; ++i, ++n) {
         RECO_CHECK_HIP(hipEventSynchronize(g_prof_ev[2 * i + 1]));
@@ -94,6 +98,7 @@ struct ProfScope {
     int slot;
     explicit ProfScope(hipStream_t st) : s(st), slot(-1)
     {
+        std::lock_guard<std::mutex> lock(g_prof_mu);
         if ((size_t)(2 * g_prof_used + 1) < g_prof_ev.size()) {
             slot = g_prof_used++;
             (void)hipEventRecord(g_prof_ev[2 * slot], s);
@@ -101,7 +106,9 @@ struct ProfScope {
     }
     ~ProfScope()
     {
-        if (slot >= 0) (void)hipEventRecord(g_prof_ev[2 * slot + 1], s);
+        if (slot < 0) return;
+        std::lock_guard<std::mutex> lock(g_prof_mu);
+        if ((size_t)(2 * slot + 1) < g_prof_ev.size()) (void)hipEventRecord(g_prof_ev[2 * slot + 1], s);
     }
 };
 
@@ -190,6 +197,15 @@ static int tower_project(const reco_tower* t, const float* u_rows, const int64_t
                                    RECO_ACT_NONE, 0.f, 0.f, Q, H1, t->oob, nullptr, 0, s);
         if (rc) return rc;
     }
+    return RECO_OK;
+}
+
+// the handle's packed weights live on the device that was current in reco_tower_create
+static int check_device(const reco_tower* t, const char* who)
+{
+    int dev = -1;
+    RECO_CHECK_HIP(hipGetDevice(&dev));
+    RECO_REQUIRE(dev == t->device, "%s: handle belongs to device %d but device %d is current", who, t->device, dev);
     return RECO_OK;
 }
 
@@ -301,6 +317,7 @@ extern "C" int reco_tower_score_pairs(reco_tower_t* t, const int64_t* user, cons
                                       float* out, void* stream)
 {
     RECO_REQUIRE(t, "score_pairs: null handle");
+    if (int rc_dev = check_device(t, "score_pairs")) return rc_dev;
     if (B <= 0) return RECO_OK;
     RECO_REQUIRE(user && item && out, "score_pairs: null pointer");
     RECO_REQUIRE(t->d.n_users > 0 && t->d.n_items > 0, "score_pairs: handle was created without embedding tables");
@@ -323,6 +340,7 @@ extern "C" int reco_tower_score_rows(reco_tower_t* t, const float* u_gmf, const 
                                      void* ws, size_t ws_bytes, void* stream)
 {
     RECO_REQUIRE(t, "score_rows: null handle");
+    if (int rc_dev = check_device(t, "score_rows")) return rc_dev;
     if (B <= 0) return RECO_OK;
     RECO_REQUIRE(out, "score_rows: null output");
     hipStream_t s = (hipStream_t)stream;
@@ -384,6 +402,7 @@ extern "C" int reco_tower_score_matrix(reco_tower_t* t, const int64_t* users, in
                                        void* ws, size_t ws_bytes, void* stream)
 {
     RECO_REQUIRE(t, "score_matrix: null handle");
+    if (int rc_dev = check_device(t, "score_matrix")) return rc_dev;
     if (U <= 0 || N <= 0) return RECO_OK;
     RECO_REQUIRE(out && ld_out >= N, "score_matrix: bad output");
     int rc = check_ranges(t, users, user_base, U, cands, N, "score_matrix");
@@ -428,6 +447,7 @@ extern "C" int reco_tower_score_topk(reco_tower_t* t, const int64_t* users, int6
                                      void* ws, size_t ws_bytes, void* stream)
 {
     RECO_REQUIRE(t, "score_topk: null handle");
+    if (int rc_dev = check_device(t, "score_topk")) return rc_dev;
     if (U <= 0) return RECO_OK;
     RECO_REQUIRE(out_ids && out_scores, "score_topk: null output");
     RECO_REQUIRE(k >= 1 && k <= 128, "score_topk: k must be in [1,128], got %d", k);

@@ -262,12 +262,8 @@ template <int BM, int BN, int VEC, bool AT>
 int launch_v(const LinArgs& a, hipStream_t s)
 {
     constexpr size_t lds = (size_t)2 * (BM + BN) * LS * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        RECO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel<BM, BN, VEC, AT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
+    static bool attr[RECO_MAX_DEVICES] = {};
+    if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&linear_kernel<BM, BN, VEC, AT>), lds, attr)) return rc;
     const int64_t blocks = ceil_div64(a.M, BM) * ceil_div64(a.N, BN) * a.splits;
     RECO_REQUIRE(blocks < (1ll << 31), "linear grid too large");
     hipLaunchKernelGGL((linear_kernel<BM, BN, VEC, AT>), dim3((unsigned)blocks), dim3(256), lds, s, a);

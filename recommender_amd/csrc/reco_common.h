@@ -29,6 +29,20 @@ void reco_set_error(const char* fmt, ...);
 
 #define RECO_CHECK_LAUNCH() RECO_CHECK_HIP(hipGetLastError())
 
+// Raises a kernel's dynamic-LDS limit once per device (the attribute is per device; `done` is the caller's
+// function-local table, one per kernel instantiation).
+constexpr int RECO_MAX_DEVICES = 64;
+static inline int reco_allow_lds(const void* kernel, size_t bytes, bool* done)
+{
+    int dev = 0;
+    RECO_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= RECO_MAX_DEVICES || !done[dev]) {
+        RECO_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        if (dev >= 0 && dev < RECO_MAX_DEVICES) done[dev] = true;
+    }
+    return RECO_OK;
+}
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

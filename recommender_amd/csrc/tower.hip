@@ -417,10 +417,10 @@ int launch_tile_t(const TileArgs& a, hipStream_t s)
 {
     constexpr size_t lds = (size_t)(IMG_SIZE + 2 * (TI * QS + (G > 0 ? TI * (G + 4) : 0))) * sizeof(float);
     static_assert(lds <= 160 * 1024, "tile kernel LDS budget");
-    static int n_cu = 0;
+    static bool attr[RECO_MAX_DEVICES] = {};
+    if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&tower_tile_kernel<G, L3>), lds, attr)) return rc;
+    static int n_cu = 0;                                  // one GPU model per node: the CU count is the same on every device
     if (n_cu == 0) {
-        RECO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_tile_kernel<G, L3>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int dev = 0;
         RECO_CHECK_HIP(hipGetDevice(&dev));
         RECO_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -437,12 +437,8 @@ template <int G, bool L3>
 int launch_pairs_t(const PairArgs& a, hipStream_t s)
 {
     constexpr size_t lds = (size_t)(IMG_SIZE + 4 * (32 * QS + (G > 0 ? 32 * (G + 4) : 0))) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        RECO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_pairs_kernel<G, L3>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static bool attr[RECO_MAX_DEVICES] = {};
+    if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&tower_pairs_kernel<G, L3>), lds, attr)) return rc;
     const int64_t nchunks = ceil_div64(a.B, 128);
     const unsigned grid = (unsigned)(nchunks < 256 ? nchunks : 256);   // persistent: one 4-wave workgroup per CU
     hipLaunchKernelGGL((tower_pairs_kernel<G, L3>), dim3(grid), dim3(256), lds, s, a);
