@@ -138,20 +138,27 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
     const int64_t nt = (Kl + BK - 1) / BK;
     const bool ragged = (Kl % BK) != 0;
     f32x4 ra[RA], rb[RB];
-    // transposed A ([K, M] storage): a k-row of the tile is BM contiguous floats; thread -> (k row tk + KPP*s, float4 tc along m)
-    constexpr int CPR = BM / 4, KPP = 256 / CPR;
-    const int tc = tid % CPR, tk = tid / CPR;
+    // transposed A ([K, M] storage): a k-row of the tile is BM contiguous floats.  Thread -> (m block of 4 = tc, RA consecutive
+    // k rows starting at RA * tkb): RA coalesced float4 loads along m, then the 4 x RA block is written k-major per m row
+    // (one ds_write_b128 / b64 per row) -- the same [m][k] image as the plain path, transposed in registers.
+    constexpr int CPR = BM / 4;
+    const int tc = tid % CPR, tkb = tid / CPR;
     const bool at_vec = AT && (a.lda % 4 == 0) && ((uintptr_t)a.A % 16 == 0) && (m0 + BM <= a.M);
+    const bool at_vec2 = AT && (a.lda % 2 == 0) && ((uintptr_t)a.A % 8 == 0) && (m0 % 2 == 0) && (m0 + BM <= a.M);   // lda = 3706
 
     auto load_a_trans = [&](int64_t k0, bool guard_k) {
 #pragma unroll
         for (int s = 0; s < RA; ++s) {
-            const int64_t k = k0 + tk + KPP * s;
+            const int64_t k = k0 + RA * tkb + s;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (!guard_k || k < Kl) {
                 const float* src = a.A + (kb + k) * a.lda + m0 + 4 * tc;
                 if (at_vec) {
                     v = *reinterpret_cast<const f32x4*>(src);
+                } else if (at_vec2) {
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    const f32x2 p0 = *reinterpret_cast<const f32x2*>(src), p1 = *reinterpret_cast<const f32x2*>(src + 2);
+                    v = f32x4{p0.x, p0.y, p1.x, p1.y};
                 } else {
                     const int64_t left = a.M - (m0 + 4 * tc);
                     if (left > 0) v.x = src[0];
@@ -186,11 +193,16 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
     auto store_tile = [&](int buf) {
         float* s_a = smem + buf * BUF;
         float* s_b = s_a + BM * LS;
-        if constexpr (AT) {   // transposing store: [m][k] image from k-major registers
+        if constexpr (AT) {   // [m][k] image from k-major registers: row 4 tc + i gets element i of each of the RA loads
 #pragma unroll
-            for (int s = 0; s < RA; ++s) {
-                float* d = s_a + (4 * tc) * LS + tk + KPP * s;
-                d[0] = ra[s].x; d[LS] = ra[s].y; d[2 * LS] = ra[s].z; d[3 * LS] = ra[s].w;
+            for (int i4 = 0; i4 < 4; ++i4) {
+                float* d = s_a + (4 * tc + i4) * LS + RA * tkb;
+                if constexpr (RA == 4) {
+                    *reinterpret_cast<f32x4*>(d) = f32x4{ra[0][i4], ra[1][i4], ra[2][i4], ra[3][i4]};
+                } else {
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<f32x2*>(d) = f32x2{ra[0][i4], ra[1][i4]};
+                }
             }
         } else {
 #pragma unroll

@@ -321,14 +321,22 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tower_tile_split_kernel(TileA
             const f32x4* prow = reinterpret_cast<const f32x4*>(a.P + u * H1 + 8 * h);
 #pragma unroll
             for (int s = 0; s < 8; ++s) { p[2 * s] = prow[4 * s]; p[2 * s + 1] = prow[4 * s + 1]; }
-            f32x4 gu[G > 0 ? G / 8 : 1];
+            // the user's GMF row, pre-multiplied by the predict weights: registers for G = 32; for G = 64 (Hybrid head) the
+            // 32 VGPRs would spill, so the wave parks the row in its own LDS slot (same-wave LDS ops execute in order)
+            constexpr bool GU_LDS = G > 32;
+            f32x4 gu[(G > 0 && !GU_LDS) ? G / 8 : 1];
+            float* s_gu = s_buf + 2 * BUF + wave * (G > 0 ? G : 1);
             if constexpr (G > 0) {
                 const int64_t uid = clamp_id(a.users ? a.users[u] : a.user_base + u, a.n_users,
                                              (lane == 0 && n0 == 0) ? a.oob : nullptr);
                 const f32x4* gr = reinterpret_cast<const f32x4*>(a.EUg + uid * G + h * (G / 2));
                 const float* wpg = s_tail + TAIL_WPG + h * (G / 2);
 #pragma unroll
-                for (int c = 0; c < G / 8; ++c) gu[c] = gr[c] * *reinterpret_cast<const f32x4*>(wpg + 4 * c);
+                for (int c = 0; c < G / 8; ++c) {
+                    const f32x4 v = gr[c] * *reinterpret_cast<const f32x4*>(wpg + 4 * c);
+                    if constexpr (GU_LDS) { if (j == 0) *reinterpret_cast<f32x4*>(s_gu + h * (G / 2) + 4 * c) = v; }
+                    else gu[c] = v;
+                }
             }
 #pragma unroll 1
             for (int g = 0; g < TI / 32; ++g) {
@@ -353,10 +361,13 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tower_tile_split_kernel(TileA
 #pragma unroll
                     for (int c = 0; c < G / 8; ++c) {
                         const f32x4 gi = *reinterpret_cast<const f32x4*>(grow + 4 * c);
-                        part = fmaf(gu[c].x, gi.x, part);
-                        part = fmaf(gu[c].y, gi.y, part);
-                        part = fmaf(gu[c].z, gi.z, part);
-                        part = fmaf(gu[c].w, gi.w, part);
+                        f32x4 gv;
+                        if constexpr (GU_LDS) gv = *reinterpret_cast<const f32x4*>(s_gu + h * (G / 2) + 4 * c);
+                        else gv = gu[c];
+                        part = fmaf(gv.x, gi.x, part);
+                        part = fmaf(gv.y, gi.y, part);
+                        part = fmaf(gv.z, gi.z, part);
+                        part = fmaf(gv.w, gi.w, part);
                     }
                 }
                 const float total = part + __shfl_xor(part, 32) + a.bp;
@@ -440,7 +451,7 @@ __global__ __launch_bounds__(256, 1) void tower_pairs_split_kernel(PairArgs a)
 template <int G, bool L3>
 int launch_tile_split_t(const TileArgs& a, hipStream_t s)
 {
-    constexpr size_t lds = (size_t)spl_bytes(L3) + (size_t)(2 * (TI * QS + (G > 0 ? TI * (G + 4) : 0))) * sizeof(float);
+    constexpr size_t lds = (size_t)spl_bytes(L3) + (size_t)(2 * (TI * QS + (G > 0 ? TI * (G + 4) : 0)) + (G > 32 ? 8 * G : 0)) * sizeof(float);
     static_assert(lds <= 160 * 1024, "split tile kernel LDS budget");
     static bool attr[RECO_MAX_DEVICES] = {};
     if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&tower_tile_split_kernel<G, L3>), lds, attr)) return rc;

@@ -76,6 +76,8 @@ def bench_autorec():
     h = ops.linear(X, we, be, "sigmoid")
     ms = timeit(lambda: ops.linear(X, we, be, "sigmoid"))
     emit("linear_kernel (AutoRec encoder)", "M=3706 N=500 K=6040", ms, "mfma", 2 * 3706 * 6040 * 500, "2*M*N*K")
+    ms = timeit(lambda: ops.linear(R, we, be, "sigmoid", x_transposed=True))
+    emit("linear_kernel (AutoRec encoder, A read transposed from R[users,items])", "M=3706 N=500 K=6040", ms, "mfma", 2 * 3706 * 6040 * 500, "2*M*N*K")
     ms = timeit(lambda: ops.linear(h, wd, bd, "clamp", 1.0, 5.0))
     emit("linear_kernel (AutoRec decoder)", "M=3706 N=6040 K=500", ms, "mfma", 2 * 3706 * 6040 * 500, "2*M*N*K")
     A = torch.randn(4096, 4096, device=dev); W = torch.randn(4096, 4096, device=dev)
