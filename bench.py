@@ -6,7 +6,8 @@
 
 One step = one pass of the hot path over one batch: every rank scores its 6,038 users against the
 3,533-item catalog (21,332,254 pairs: layer-1 projections + fused tower + top-10 select), then all ranks
-all-gather the top-10 lists over RCCL.  Weights: NeuMF-end random init (reference constructor order,
+all-gather the top-10 lists over RCCL (one packed message; the gather of step i overlaps the kernels of step i + 1, and the
+last gather is inside the timed region).  Weights: NeuMF-end random init (reference constructor order,
 torch.manual_seed(0)); at N > 1 the user table has N x 6,038 rows, replicated, user-sharded (weak scaling).
 Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 """
@@ -102,7 +103,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     from recommender_amd import _lib
-    from recommender_amd.dist import sharded_score_topk, shard_range
+    from recommender_amd.dist import TopkGather, shard_range
 
     from recommender_amd import ops
 
@@ -121,16 +122,16 @@ def main():
     def timed_run(precision):
         """W warm-up steps, then K timed steps between fences; (seconds max over ranks, mean ms of the tile kernel, ids, vals)."""
         ops.set_tower_precision(precision)
-        tower = model._tower(device)
-        ws = tower.topk_workspace(count, N_ITEMS, K)
-        out = (torch.empty((count, K), dtype=torch.int32, device=device), torch.empty((count, K), dtype=torch.float32, device=device))
+        pipe = TopkGather(model, K, total_users)      # step i's all-gather overlaps step i + 1's kernels
         for _ in range(args.warmup):
-            ids, vals = sharded_score_topk(model, K, total_users, ws=ws, out=out)
+            pipe.step()
+        pipe.flush()
         _lib.check(L.reco_profile_enable(args.steps + 4))
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            ids, vals = sharded_score_topk(model, K, total_users, ws=ws, out=out)
+            pipe.step()
+        ids, vals = pipe.flush()
         fence()
         el = time.perf_counter() - t0
         ms = (ctypes.c_float * (args.steps + 4))()

@@ -2,8 +2,11 @@
 
 One process per GPU (torchrun / torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" in the CPU tests).
 Tables and weights are replicated; every rank scores a contiguous user range against the whole catalog;
-the only data-path collective is ONE all-gather of the per-user top-k lists (k x 8 bytes per user).
-With user sharding the lists are disjoint, so the "merge" is a concatenation in rank order.
+the only data-path collective is ONE all-gather of the per-user top-k lists (k x 8 bytes per user: ids and scores travel
+in one packed int32 buffer).  With user sharding the lists are disjoint, so the "merge" is a concatenation in rank order.
+
+`TopkGather` keeps that collective off the critical path: the gather of step i runs on RCCL's stream while the scoring
+kernels of step i + 1 run on the compute stream (two packed buffers in flight).
 """
 import torch
 import torch.distributed as dist
@@ -16,11 +19,46 @@ def shard_range(total, rank, world):
     return start, q + (1 if rank < r else 0)
 
 
-def all_gather_topk(ids, vals, counts=None, group=None):
-    """Concatenate per-rank (ids [u_r,k], vals [u_r,k]) into ([U,k], [U,k]) on every rank.
+def packed_topk_buffers(rows, k, device):
+    """(buf int32 [2, rows, k], ids view int32 [rows, k], scores view float32 [rows, k]): scoring writes straight into the
+    two halves, the gather sends `buf` as one message."""
+    buf = torch.empty((2, rows, k), dtype=torch.int32, device=device)
+    return buf, buf[0], buf[1].view(torch.float32)
 
-    counts: list of per-rank row counts (needed when they differ: ranks pad to the maximum and the
-    padding is dropped after the gather).  Equal counts use all_gather_into_tensor directly.
+
+def _is_packed(ids, vals):
+    return (ids.dtype == torch.int32 and vals.dtype == torch.float32 and ids.is_contiguous() and vals.is_contiguous()
+            and ids.shape == vals.shape and ids.untyped_storage().data_ptr() == vals.untyped_storage().data_ptr()
+            and vals.data_ptr() == ids.data_ptr() + ids.numel() * 4)
+
+
+def _pack(ids, vals, rows):
+    """[2, rows, k] int32 holding ids and the bit pattern of vals, zero-padded to `rows`."""
+    n, k = ids.shape
+    if n == rows and _is_packed(ids, vals):
+        return torch.as_strided(ids, (2, rows, k), (rows * k, k, 1))
+    buf = torch.zeros((2, rows, k), dtype=torch.int32, device=ids.device)
+    buf[0, :n] = ids.to(torch.int32)
+    buf[1, :n] = vals.to(torch.float32).contiguous().view(torch.int32)
+    return buf
+
+
+def _unpack(gathered, counts, k):
+    """gathered int32 [world, 2, mx, k] -> (ids [U, k], vals [U, k]) in user order, per-rank padding dropped."""
+    if all(c == gathered.shape[2] for c in counts):
+        ids = gathered[:, 0].reshape(-1, k)
+        vals = gathered[:, 1].reshape(-1, k)
+    else:
+        ids = torch.cat([gathered[r, 0, :c] for r, c in enumerate(counts)])
+        vals = torch.cat([gathered[r, 1, :c] for r, c in enumerate(counts)])
+    return ids, vals.contiguous().view(torch.float32)
+
+
+def all_gather_topk(ids, vals, counts=None, group=None):
+    """Concatenate per-rank (ids [u_r,k], vals [u_r,k]) into ([U,k], [U,k]) on every rank with one collective.
+
+    counts: list of per-rank row counts (needed when they differ: ranks pad to the maximum and the padding is dropped
+    after the gather).  ids / vals that are the two halves of packed_topk_buffers() are sent in place.
     """
     if not dist.is_initialized():
         return ids, vals
@@ -29,16 +67,10 @@ def all_gather_topk(ids, vals, counts=None, group=None):
     if counts is None:
         counts = [ids.shape[0]] * world
     mx = max(counts)
-    if ids.shape[0] < mx:                                   # pad to a common shape
-        pad = mx - ids.shape[0]
-        ids = torch.cat([ids, ids.new_zeros((pad, k))]); vals = torch.cat([vals, vals.new_zeros((pad, k))])
-    out_i = ids.new_empty((world * mx, k)); out_v = vals.new_empty((world * mx, k))
-    dist.all_gather_into_tensor(out_i, ids.contiguous(), group=group)
-    dist.all_gather_into_tensor(out_v, vals.contiguous(), group=group)
-    if all(c == mx for c in counts):
-        return out_i, out_v
-    keep = torch.cat([torch.arange(r * mx, r * mx + c, device=ids.device) for r, c in enumerate(counts)])
-    return out_i.index_select(0, keep), out_v.index_select(0, keep)
+    buf = _pack(ids, vals, mx)
+    out = torch.empty((world * 2, mx, k), dtype=torch.int32, device=ids.device)    # concatenation along dim 0
+    dist.all_gather_into_tensor(out, buf, group=group)
+    return _unpack(out.view(world, 2, mx, k), counts, k)
 
 
 def sharded_score_topk(model, k, total_users=None, candidates=None, group=None, ws=None, out=None):
@@ -57,3 +89,64 @@ def sharded_score_topk(model, k, total_users=None, candidates=None, group=None, 
         return ids, vals
     counts = [shard_range(U, r, world)[1] for r in range(world)]
     return all_gather_topk(ids, vals, counts, group)
+
+
+class TopkGather:
+    """Pipelined form of sharded_score_topk for back-to-back steps.
+
+        pipe = TopkGather(model, k, total_users)
+        for _ in range(steps):
+            done = pipe.step()          # result of the PREVIOUS step (None on the first call), already gathered
+        last = pipe.flush()             # result of the last step
+
+    step() enqueues this rank's scoring + top-k into one of two packed buffers and starts the all-gather of that buffer
+    asynchronously; the gather overlaps the next step's kernels.  Results are (ids [U,k], scores [U,k]) in user order.
+    A result may alias a pipeline buffer: it stays valid until two further step() calls.
+    Without an initialised process group it degenerates to the local call.
+    """
+
+    def __init__(self, model, k, total_users=None, candidates=None, group=None):
+        self.k, self.candidates, self.group = k, candidates, group
+        self.on = dist.is_initialized()
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.device = model._compute_device()
+        self.tower = model._tower(self.device)
+        U = self.tower.n_users if total_users is None else int(total_users)
+        self.start, self.count = shard_range(U, self.rank, self.world)
+        self.counts = [shard_range(U, r, self.world)[1] for r in range(self.world)]
+        mx = max(self.counts)
+        n_items = self.tower.n_items if candidates is None else len(candidates)
+        self.ws = self.tower.topk_workspace(self.count, n_items, k)
+        self.slots = []
+        for _ in range(2):
+            buf, ids, vals = packed_topk_buffers(mx, k, self.device)
+            if self.count < mx:
+                buf.zero_()
+            gathered = torch.empty((self.world * 2, mx, k), dtype=torch.int32, device=self.device) if self.on else None
+            self.slots.append({"buf": buf, "ids": ids[:self.count], "vals": vals[:self.count], "gathered": gathered, "work": None})
+        self.i = 0
+        self.pending = None
+
+    def _collect(self, slot):
+        if not self.on:
+            return slot["ids"], slot["vals"]
+        slot["work"].wait()                     # the compute stream waits for the collective; the host does not
+        slot["work"] = None
+        return _unpack(slot["gathered"].view(self.world, 2, -1, self.k), self.counts, self.k)
+
+    def step(self):
+        slot = self.slots[self.i & 1]
+        self.i += 1
+        self.tower.score_topk((self.start, self.count), self.k, self.candidates, None, check_ids=False, ws=self.ws,
+                              out=(slot["ids"], slot["vals"]))
+        if self.on:
+            slot["work"] = dist.all_gather_into_tensor(slot["gathered"], slot["buf"], group=self.group, async_op=True)
+        done = self._collect(self.pending) if self.pending is not None else None
+        self.pending = slot
+        return done
+
+    def flush(self):
+        done = self._collect(self.pending) if self.pending is not None else None
+        self.pending = None
+        return done

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from recommender_amd.dist import all_gather_topk, shard_range
+from recommender_amd.dist import TopkGather, all_gather_topk, packed_topk_buffers, shard_range
 
 
 def test_shard_range_covers_everything_contiguously():
@@ -36,17 +36,61 @@ def _worker(rank, world, port, total, k, q):
         dist.destroy_process_group()
 
 
+class _StubTower:
+    """Stands in for ops.Tower on the CPU: 'scores' a user range by writing a function of (user, step) into `out`."""
+    def __init__(self, n_users, n_items):
+        self.n_users, self.n_items, self.calls = n_users, n_items, 0
+
+    def topk_workspace(self, U, N, k):
+        return None
+
+    def score_topk(self, users, k, cands, exclude, check_ids=True, ws=None, out=None):
+        start, count = users
+        u = torch.arange(start, start + count).view(-1, 1)
+        out[0].copy_((u * 7 + torch.arange(k).view(1, -1) + self.calls).to(torch.int32))
+        out[1].copy_((u * 0.5 - torch.arange(k).view(1, -1) - self.calls).to(torch.float32))
+        self.calls += 1
+        return out
+
+
+class _StubModel:
+    def __init__(self, tower):
+        self.tower = tower
+
+    def _compute_device(self):
+        return torch.device("cpu")
+
+    def _tower(self, device):
+        return self.tower
+
+
+def _pipe_worker(rank, world, port, total, k, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pipe = TopkGather(_StubModel(_StubTower(total, 50)), k, total)
+        got = [pipe.step() for _ in range(4)] + [pipe.flush()]
+        ok = got[0] is None
+        u = torch.arange(total).view(-1, 1)
+        for step, (ids, vals) in enumerate(got[1:]):
+            ok = ok and torch.equal(ids, (u * 7 + torch.arange(k).view(1, -1) + step).to(torch.int32))
+            ok = ok and torch.equal(vals, (u * 0.5 - torch.arange(k).view(1, -1) - step).to(torch.float32))
+        q.put((rank, bool(ok), tuple(got[-1][0].shape)))
+    finally:
+        dist.destroy_process_group()
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
 
 
-def _run(total, k):
+def _run(total, k, worker=_worker):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, k, q)) for r in range(2)]
+    procs = [ctx.Process(target=worker, args=(r, 2, port, total, k, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
@@ -64,3 +108,18 @@ def test_all_gather_topk_equal_shards():
 def test_all_gather_topk_ragged_shards():
     for rank, ok, shape in _run(13, 100):      # 7 + 6 users: padded gather, padding dropped
         assert ok and shape == (13, 100)
+
+
+def test_pipelined_gather_two_buffers_in_flight_equal_and_ragged_shards():
+    for total in (12, 13):
+        for rank, ok, shape in _run(total, 10, _pipe_worker):
+            assert ok and shape == (total, 10)
+
+
+def test_packed_buffers_are_sent_in_place():
+    from recommender_amd.dist import _is_packed, _pack
+    buf, ids, vals = packed_topk_buffers(5, 3, "cpu")
+    ids.copy_(torch.arange(15, dtype=torch.int32).view(5, 3)); vals.copy_(torch.arange(15, dtype=torch.float32).view(5, 3) * 0.25)
+    assert _is_packed(ids, vals) and _pack(ids, vals, 5).data_ptr() == buf.data_ptr()
+    assert torch.equal(_pack(ids, vals, 5), buf)
+    assert not _is_packed(ids.clone(), vals) and _pack(ids[:4], vals[:4], 5).shape == (2, 5, 3)
