@@ -80,6 +80,7 @@ int reco_neumf_gather(const float* Eu_g, const float* Ei_g, const float* Eu_m, c
 #define RECO_LINEAR_A_TRANSPOSED 1   /* A is stored [K, M] with row stride lda: the item-vector batch X = R^T of
                                        inference_engine.py:230 / helper.py:283 is read straight out of R [users, items] */
 #define RECO_LINEAR_BIAS_PER_ROW 2   /* bias[m] instead of bias[n]: R_hat^T = Wd H^T + bd, no transposed copy */
+#define RECO_LINEAR_SPLIT_BF16X3 4   /* multiply as three bf16 pieces per fp32 operand on the bf16 MFMA, fp32 accumulate (see RECO_PREC_SPLIT_BF16X3) */
 size_t reco_linear_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int reco_linear_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_t a_row_limit, int64_t M,
                     const float* W, int64_t ldw, const float* bias, int64_t N, int64_t K,
@@ -93,8 +94,8 @@ int reco_linear_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_t 
 size_t reco_autorec_workspace_bytes(int64_t B, int64_t n_in, int64_t hidden);
 int reco_autorec_forward(const float* X, int64_t B, const float* We, const float* be,
                          const float* Wd, const float* bd, int64_t n_in, int64_t hidden,
-                         int act, float lo, float hi, float* hidden_ws, float* out,
-                         void* ws, size_t ws_bytes, void* stream);
+                         int act, float lo, float hi, int flags /* 0 or RECO_LINEAR_SPLIT_BF16X3 */,
+                         float* hidden_ws, float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K-b  fused scoring tower (NeuMF, MLP-only, GMF-only, Hybrid head)

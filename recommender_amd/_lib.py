@@ -42,7 +42,7 @@ _SIGNATURES = {
     "reco_linear_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "reco_autorec_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "reco_autorec_forward": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
-                                     c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                     c_int, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "reco_tower_create": (c_int, [POINTER(TowerDesc), c_void_p, POINTER(c_void_p)]),
     "reco_tower_destroy": (None, [c_void_p]),
     "reco_tower_score_pairs": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),

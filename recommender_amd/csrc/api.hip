@@ -121,7 +121,7 @@ extern "C" int reco_linear_f32(const float* A, int64_t lda, const int64_t* a_row
                                void* ws, size_t ws_bytes, void* stream)
 {
     RECO_REQUIRE(act >= RECO_ACT_NONE && act <= RECO_ACT_RATING, "linear: unknown activation %d", act);
-    RECO_REQUIRE((flags & ~3) == 0, "linear: unknown flags %d", flags);
+    RECO_REQUIRE((flags & ~7) == 0, "linear: unknown flags %d", flags);
     return launch_linear_f32(A, lda, a_rows, a_row_limit, M, W, ldw, bias, N, K, act, lo, hi, C, ldc, nullptr,
                              ws, ws_bytes, (hipStream_t)stream, flags);
 }
@@ -136,19 +136,20 @@ extern "C" size_t reco_autorec_workspace_bytes(int64_t B, int64_t n_in, int64_t 
 
 extern "C" int reco_autorec_forward(const float* X, int64_t B, const float* We, const float* be,
                                     const float* Wd, const float* bd, int64_t n_in, int64_t hidden,
-                                    int act, float lo, float hi, float* hidden_ws, float* out,
+                                    int act, float lo, float hi, int flags, float* hidden_ws, float* out,
                                     void* ws, size_t ws_bytes, void* stream)
 {
     if (B <= 0) return RECO_OK;
+    RECO_REQUIRE((flags & ~RECO_LINEAR_SPLIT_BF16X3) == 0, "autorec_forward: only RECO_LINEAR_SPLIT_BF16X3 is a valid flag, got %d", flags);
     RECO_REQUIRE(X && We && be && Wd && bd && hidden_ws && out, "autorec_forward: null pointer");
     RECO_REQUIRE(n_in > 0 && hidden > 0, "autorec_forward: bad dimensions");
     RECO_REQUIRE(act == RECO_ACT_NONE || act == RECO_ACT_CLAMP, "autorec_forward: act must be NONE or CLAMP");
     hipStream_t s = (hipStream_t)stream;
     int rc = launch_linear_f32(X, n_in, nullptr, 0, B, We, n_in, be, hidden, n_in, RECO_ACT_SIGMOID, 0.f, 0.f,
-                               hidden_ws, hidden, nullptr, ws, ws_bytes, s);
+                               hidden_ws, hidden, nullptr, ws, ws_bytes, s, flags);
     if (rc) return rc;
     return launch_linear_f32(hidden_ws, hidden, nullptr, 0, B, Wd, hidden, bd, n_in, hidden, act, lo, hi, out, n_in,
-                             nullptr, ws, ws_bytes, s);
+                             nullptr, ws, ws_bytes, s, flags);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -9,12 +9,37 @@
 // the same way: 128-B row segments -> LDS tile [rows][32 + 4 pad], read back as one ds_read_b128
 // per lane per 4 MFMA steps (k = 8 q + 4 h + jj, the same free k-permutation as tower.hip).
 // Exact fp32: each output is a k-ordered fmaf chain (guide: FP32-input MFMA numerics).
+//
+// SPLIT = true (RECO_LINEAR_SPLIT_BF16X3) is the same kernel on v_mfma_f32_32x32x16_bf16: while a tile is staged, every
+// fp32 element of A and W is split exactly into three bf16 pieces (hi + mid + lo, see tower_split.hip) that go to three
+// LDS images [rows][32 bf16 + pad]; per 16-wide k-step the six cross terms down to 2^-24 relative are accumulated in
+// fp32.  Loads, tiling, split-K, transposed A and the epilogue are shared with the exact form.
 #include "reco_common.h"
 
 namespace {
 
 constexpr int BK = 32;
 constexpr int LS = BK + 4;   // padded LDS row stride (floats): 16 rows x b128 hit 16 distinct 4-bank slots
+constexpr int LSB = 40;      // split form: row stride in bf16 (80 B): 16 rows x b128 hit 16 distinct 4-bank slots (5 i mod 16)
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b)       // one v_cvt_pk_bf16_f32 (RNE)
+{
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+// two fp32 values -> (hi, mid, lo) packed bf16 pairs; the residuals are exact
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& H, unsigned& M, unsigned& L)
+{
+    H = pk_bf16(a, b);
+    const float ra = a - __uint_as_float(H << 16), rb = b - __uint_as_float(H & 0xffff0000u);
+    M = pk_bf16(ra, rb);
+    L = pk_bf16(ra - __uint_as_float(M << 16), rb - __uint_as_float(M & 0xffff0000u));
+}
 
 struct LinArgs {
     const float* A;
@@ -76,14 +101,18 @@ __device__ __forceinline__ f32x4 load_k4(const float* row, int64_t k, int64_t K)
 // K is consumed in BK = 32 tiles through a double-buffered LDS image: the global loads of tile t+1 are issued before
 // the MFMAs of tile t and written to the other buffer after them -- one barrier per tile, no branch in the steady state
 // (rows past M / N are clamped to the last row and discarded at the store; only the ragged last K tile is guarded).
-template <int BM, int BN, int VEC, bool AT>
+template <int BM, int BN, int VEC, bool AT, bool SPLIT>
 __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
 {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int RA = BM / 32, RB = BN / 32;   // float4 per thread per operand per K tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // layout: [buf][A tile BM*LS | B tile BN*LS]
-    constexpr int BUF = (BM + BN) * LS;
+    // layout: [buf][A tile BM*LS | B tile BN*LS] floats;  split form: [buf][piece(3)][A tile BM*LSB | B tile BN*LSB] bf16
+    constexpr int BUF = SPLIT ? 3 * (BM + BN) * LSB / 2 : (BM + BN) * LS;      // in floats
+    constexpr int PIECE = (BM + BN) * LSB;                                      // bf16 per piece image
+    // split form: ONE LDS image (61 KB at 128x128), so two workgroups share a CU and one's staging (global loads, operand
+    // splitting, LDS writes) overlaps the other's MFMAs; the exact form double-buffers inside the workgroup instead
+    constexpr int NBUF = SPLIT ? 1 : 2;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -176,10 +205,10 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
             if constexpr (AT) load_a_trans(k0, true);
             else {
 #pragma unroll
-                for (int s = 0; s < RA; ++s) ra[s] = load_k4<1, true>(arow[s], k0, Kl - 4 * sc);
+                for (int s = 0; s < RA; ++s) ra[s] = load_k4<VEC, true>(arow[s], k0, Kl - 4 * sc);
             }
 #pragma unroll
-            for (int s = 0; s < RB; ++s) rb[s] = load_k4<1, true>(wrow[s], k0, Kl - 4 * sc);
+            for (int s = 0; s < RB; ++s) rb[s] = load_k4<VEC, true>(wrow[s], k0, Kl - 4 * sc);
         } else {
             if constexpr (AT) load_a_trans(k0, false);
             else {
@@ -191,6 +220,40 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
         }
     };
     auto store_tile = [&](int buf) {
+        if constexpr (SPLIT) {
+            unsigned short* base = reinterpret_cast<unsigned short*>(smem + buf * BUF);
+            // a thread's RA (RB) register groups hold 4 (AT with BM = 64: 2) consecutive k of one row each
+            auto put4 = [&](unsigned short* row, f32x4 v) {
+                unsigned h0, m0, l0, h1, m1, l1;
+                split_pair(v.x, v.y, h0, m0, l0);
+                split_pair(v.z, v.w, h1, m1, l1);
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<u32x2*>(row) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2*>(row + PIECE) = u32x2{m0, m1};
+                *reinterpret_cast<u32x2*>(row + 2 * PIECE) = u32x2{l0, l1};
+            };
+            if constexpr (AT) {
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    unsigned short* row = base + (4 * tc + i4) * LSB + RA * tkb;
+                    if constexpr (RA == 4) {
+                        put4(row, f32x4{ra[0][i4], ra[1][i4], ra[2][i4], ra[3][i4]});
+                    } else {
+                        unsigned h, m, l;
+                        split_pair(ra[0][i4], ra[1][i4], h, m, l);
+                        *reinterpret_cast<unsigned*>(row) = h;
+                        *reinterpret_cast<unsigned*>(row + PIECE) = m;
+                        *reinterpret_cast<unsigned*>(row + 2 * PIECE) = l;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < RA; ++s) put4(base + (sr + 32 * s) * LSB + 4 * sc, ra[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < RB; ++s) put4(base + BM * LSB + (sr + 32 * s) * LSB + 4 * sc, rb[s]);
+            return;
+        }
         float* s_a = smem + buf * BUF;
         float* s_b = s_a + BM * LS;
         if constexpr (AT) {   // [m][k] image from k-major registers: row 4 tc + i gets element i of each of the RA loads
@@ -218,6 +281,30 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
 
     for (int64_t t = 0; t < nt; ++t) {
         if (t + 1 < nt) load_tile(t + 1);
+        if constexpr (SPLIT) {
+            const unsigned short* pa = reinterpret_cast<const unsigned short*>(smem + (t & (NBUF - 1)) * BUF) + (wm * (BM / 2) + i) * LSB + 8 * h;
+            const unsigned short* pb = reinterpret_cast<const unsigned short*>(smem + (t & (NBUF - 1)) * BUF) + BM * LSB + (wn * (BN / 2) + i) * LSB + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) fa[tm][c] = *reinterpret_cast<const bf16x8*>(pa + c * PIECE + tm * 32 * LSB + 16 * ks);
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) fb[tn][c] = *reinterpret_cast<const bf16x8*>(pb + c * PIECE + tn * 32 * LSB + 16 * ks);
+                }
+                // six cross terms, smallest first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+                constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int term = 0; term < 6; ++term)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][ta[term]], fb[tn][tb[term]], acc[tm][tn], 0, 0, 0);
+            }
+        } else {
         const float* s_a = smem + (t & 1) * BUF + (wm * (BM / 2) + i) * LS + 4 * h;
         const float* s_b = smem + (t & 1) * BUF + BM * LS + (wn * (BN / 2) + i) * LS + 4 * h;
 #pragma unroll
@@ -235,7 +322,13 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
                     for (int tn = 0; tn < TN; ++tn)
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm][jj], fb[tn][jj], acc[tm][tn], 0, 0, 0);
         }
-        if (t + 1 < nt) store_tile((t + 1) & 1);
+        }
+        if constexpr (NBUF == 1) {
+            __syncthreads();                       // every wave is done reading the image
+            if (t + 1 < nt) store_tile(0);
+        } else {
+            if (t + 1 < nt) store_tile((t + 1) & 1);
+        }
         __syncthreads();
     }
 
@@ -270,15 +363,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(LinArgs a)
     }
 }
 
-template <int BM, int BN, int VEC, bool AT>
+template <int BM, int BN, int VEC, bool AT, bool SPLIT>
 int launch_v(const LinArgs& a, hipStream_t s)
 {
-    constexpr size_t lds = (size_t)2 * (BM + BN) * LS * sizeof(float);
+    constexpr size_t lds = SPLIT ? (size_t)3 * (BM + BN) * LSB * 2 : (size_t)2 * (BM + BN) * LS * sizeof(float);
     static bool attr[RECO_MAX_DEVICES] = {};
-    if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&linear_kernel<BM, BN, VEC, AT>), lds, attr)) return rc;
+    if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&linear_kernel<BM, BN, VEC, AT, SPLIT>), lds, attr)) return rc;
     const int64_t blocks = ceil_div64(a.M, BM) * ceil_div64(a.N, BN) * a.splits;
     RECO_REQUIRE(blocks < (1ll << 31), "linear grid too large");
-    hipLaunchKernelGGL((linear_kernel<BM, BN, VEC, AT>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((linear_kernel<BM, BN, VEC, AT, SPLIT>), dim3((unsigned)blocks), dim3(256), lds, s, a);
     RECO_CHECK_LAUNCH();
     if (a.splits > 1) {
         const int64_t rb = ceil_div64(a.M * a.N, 256);
@@ -288,17 +381,26 @@ int launch_v(const LinArgs& a, hipStream_t s)
     return RECO_OK;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool SPLIT>
 int launch_t(const LinArgs& a, int vec, hipStream_t s)
 {
     if (a.a_trans) {
-        if (vec == 4) return launch_v<BM, BN, 4, true>(a, s);
-        if (vec == 2) return launch_v<BM, BN, 2, true>(a, s);
-        return launch_v<BM, BN, 1, true>(a, s);
+        if (vec == 4) return launch_v<BM, BN, 4, true, SPLIT>(a, s);
+        if (vec == 2) return launch_v<BM, BN, 2, true, SPLIT>(a, s);
+        return launch_v<BM, BN, 1, true, SPLIT>(a, s);
     }
-    if (vec == 4) return launch_v<BM, BN, 4, false>(a, s);
-    if (vec == 2) return launch_v<BM, BN, 2, false>(a, s);
-    return launch_v<BM, BN, 1, false>(a, s);
+    if (vec == 4) return launch_v<BM, BN, 4, false, SPLIT>(a, s);
+    if (vec == 2) return launch_v<BM, BN, 2, false, SPLIT>(a, s);
+    return launch_v<BM, BN, 1, false, SPLIT>(a, s);
+}
+
+template <bool SPLIT>
+int launch_tile(const LinArgs& a, int bm, int bn, int vec, hipStream_t s)
+{
+    if (bm == 128 && bn == 128) return launch_t<128, 128, SPLIT>(a, vec, s);
+    if (bm == 128) return launch_t<128, 64, SPLIT>(a, vec, s);
+    if (bn == 128) return launch_t<64, 128, SPLIT>(a, vec, s);
+    return launch_t<64, 64, SPLIT>(a, vec, s);
 }
 
 // rough utilisation model: larger tiles amortise LDS traffic better, but the grid must cover the 256 CUs
@@ -365,8 +467,6 @@ int launch_linear_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_
             if (a.splits <= 1) { a.splits = 1; a.k_per_split = K; a.partial = nullptr; }
         }
     }
-    if (bm == 128 && bn == 128) return launch_t<128, 128>(a, vec, s);
-    if (bm == 128) return launch_t<128, 64>(a, vec, s);
-    if (bn == 128) return launch_t<64, 128>(a, vec, s);
-    return launch_t<64, 64>(a, vec, s);
+    if (flags & RECO_LINEAR_SPLIT_BF16X3) return launch_tile<true>(a, bm, bn, vec, s);
+    return launch_tile<false>(a, bm, bn, vec, s);
 }

@@ -103,11 +103,12 @@ def neumf_gather(eu_g, ei_g, eu_m, ei_m, user, item, check_ids=True, gmf_out=Non
 # ----------------------------------------------------------------------------------------------
 # K-c Linear / AutoRec
 # ----------------------------------------------------------------------------------------------
-def linear(x, weight, bias=None, act=None, lo=0.0, hi=0.0, out=None, x_transposed=False, bias_per_row=False):
+def linear(x, weight, bias=None, act=None, lo=0.0, hi=0.0, out=None, x_transposed=False, bias_per_row=False, precision=None):
     """act(x @ weight.T + bias) on the fp32 MFMA GEMM (nn.Linear + fused activation).
 
     x_transposed: x is given as [K, M] (the kernel reads it transposed: no .t().contiguous() copy);
-    bias_per_row: bias has M entries and is added per output row.
+    bias_per_row: bias has M entries and is added per output row;
+    precision: "f32" / "bf16x3" (None: the process-wide setting, see set_tower_precision).
     """
     if isinstance(x, torch.Tensor) and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1 \
             and x.stride(0) >= x.shape[1]:
@@ -131,14 +132,14 @@ def linear(x, weight, bias=None, act=None, lo=0.0, hi=0.0, out=None, x_transpose
     nbytes = L.reco_linear_workspace_bytes(M, N, K)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
     lda = x.stride(0) if x.shape[0] > 1 else x.shape[1]
-    flags = (1 if x_transposed else 0) | (2 if bias_per_row else 0)
+    flags = (1 if x_transposed else 0) | (2 if bias_per_row else 0) | (4 if PRECISIONS[precision or tower_precision()] else 0)
     with torch.cuda.device(x.device):
         check(L.reco_linear_f32(_p(x), lda, None, 0, M, _p(weight), K, _p(bias), N, K, ACTS[act], lo, hi,
                                 _p(out), out.stride(0) if M > 1 else N, flags, _p(ws), nbytes, _stream(x.device)))
     return out
 
 
-def autorec_forward(x, we, be, wd, bd, clamp=None):
+def autorec_forward(x, we, be, wd, bd, clamp=None, precision=None):
     """decoder(sigmoid(encoder(x))) (+clamp) -- src/autorec/utils/model.py:31-33, inference_engine.py:232."""
     x = _f32(x, "input", 2)
     we = _f32(we, "encoder.0.weight", 2); be = _f32(be, "encoder.0.bias", 1)
@@ -155,6 +156,7 @@ def autorec_forward(x, we, be, wd, bd, clamp=None):
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
     with torch.cuda.device(x.device):
         check(L.reco_autorec_forward(_p(x), B, _p(we), _p(be), _p(wd), _p(bd), n_in, hidden, act, lo, hi,
+                                     4 if PRECISIONS[precision or tower_precision()] else 0,
                                      _p(h), _p(out), _p(ws), nbytes, _stream(x.device)))
     return out
 

@@ -43,7 +43,7 @@ def test_ncf_engine_matches_reference_engine_semantics(g2):
     assert e.value.status_code == 503
 
 
-def test_autorec_engine_serves_from_cached_hidden_layer(g3):
+def test_autorec_engine_serves_from_cached_hidden_layer(g3, tower_precision):
     from recommender_amd.api_core import AutoRecInferenceEngine, RequestError
     from recommender_amd.autorec.utils.model import AutoRec
     m = AutoRec(193, 89, 64, True)
@@ -83,7 +83,7 @@ def test_evaluate_protocol_real_gmf(g1):
     assert np.array_equal(hr_c.astype(np.uint8), g1["hr"])
 
 
-def test_autorec_and_hybrid_ranking_evaluators(g3, g4):
+def test_autorec_and_hybrid_ranking_evaluators(g3, g4, tower_precision):
     from recommender_amd.autorec.utils.model import AutoRec
     from recommender_amd.evaluate import autorec_ranking_metrics, hybrid_ranking_metrics
     from recommender_amd.hybridautorecncf.model import HybridAutoRecNCF

@@ -91,7 +91,7 @@ def test_cfg1_full_protocol_size_pair_list(tower_precision):
     assert abs(hr[sl].mean() - ohr.mean()) <= 1.0 / 4096 and abs(nd[sl].mean() - ond.mean()) <= 1e-3
 
 
-def test_cfg3_autorec_full_reconstruction_and_masked_topk():
+def test_cfg3_autorec_full_reconstruction_and_masked_topk(tower_precision):
     from recommender_amd.autorec.utils.model import AutoRec
     torch.manual_seed(0)
     m = AutoRec(6040, 3706, 500, True).eval()
@@ -114,7 +114,11 @@ def test_cfg3_autorec_full_reconstruction_and_masked_topk():
     ref64 = O.autorec_forward(sd64, train.T[rows], np.float64)
     assert_close(got[rows], ref64, atol=4e-6, what="cfg3 rows vs oracle fp64")
     ids, vals = m.recommend_topk(torch.from_numpy(train).cuda(), 10)
-    pred = np.clip(got, 1.0, 5.0).T
+    # reconstruct_all reads R transposed and swaps the operand roles in the decoder (no transposed copies)
+    pred = m.reconstruct_all(torch.from_numpy(train).cuda()).cpu().numpy()
+    assert_close(pred, np.clip(got, 1.0, 5.0).T, atol=4e-6, what="cfg3 reconstruct_all vs forward")
+    if tower_precision == "f32":            # exact mode: both are the same k-ordered fmaf chains, bit for bit
+        assert np.array_equal(pred, np.clip(got, 1.0, 5.0).T)
     oid, oval = O.topk_rows(O.mask_seen(np.ascontiguousarray(pred), train > 0), 10)
     assert np.array_equal(vals.cpu().numpy(), oval)
     assert np.array_equal(ids.cpu().numpy(), oid)                  # clamp plateaus: ties resolved by ascending item id

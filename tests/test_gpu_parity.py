@@ -72,7 +72,7 @@ def test_g2_small_models_pairs_matrix_topk(g2, tag, tower_precision):
 
 
 @pytest.mark.parametrize("tag", ["f16l2", "f64l3", "f8l4", "f128l1", "f64gmf"])
-def test_g2b_other_tower_shapes_run_on_the_unfused_hip_path(g2b, tag):
+def test_g2b_other_tower_shapes_run_on_the_unfused_hip_path(g2b, tag, tower_precision):
     """factor_num / num_layers other than the shipped 32 x 3 (ncf-embedding.ipynb sweeps 8..128)."""
     from recommender_amd.helpers import NCF
     sd = golden_sd(g2b, tag)
@@ -153,7 +153,7 @@ def test_g2r_rating_variants(g2r, tower_precision):
         assert_close(s.reshape(ref.shape), ref, what=tag + " rating pairs")
 
 
-def test_g3_autorec(g3):
+def test_g3_autorec(g3, tower_precision):
     from recommender_amd.autorec.utils.model import AutoRec
     for tag, (U, I, H) in (("a", (193, 89, 64)), ("b", (61, 37, 500))):
         sd = golden_sd(g3, tag)
@@ -183,7 +183,7 @@ def test_g3_autorec(g3):
             assert_close(m.predict_user(u).cpu().numpy(), g3[tag + "__clamped"][:, u], atol=atol, what="predict_user")
 
 
-def test_g3_tie_storm(g3):
+def test_g3_tie_storm(g3, tower_precision):
     from recommender_amd import ops
     ids, vals = ops.topk_rows(torch.from_numpy(g3["tie__scores"]).cuda(), 100)
     assert np.array_equal(ids.cpu().numpy(), g3["tie__api_top100"])
@@ -250,7 +250,7 @@ def test_gather_kernels():
         ops.gather_rows(c(eu_m), c(np.array([0, 1000])))
 
 
-def test_linear_shapes_and_epilogues():
+def test_linear_shapes_and_epilogues(tower_precision):
     from recommender_amd import ops
     rng = np.random.default_rng(6)
     for M, N, K in ((1, 1, 1), (7, 5, 3), (130, 70, 33), (300, 500, 6040 // 8), (257, 129, 100), (64, 64, 32), (100, 6, 3706 // 2 + 1),

@@ -80,7 +80,17 @@ def bench_autorec():
     emit("linear_kernel (AutoRec encoder, A read transposed from R[users,items])", "M=3706 N=500 K=6040", ms, "mfma", 2 * 3706 * 6040 * 500, "2*M*N*K")
     ms = timeit(lambda: ops.linear(h, wd, bd, "clamp", 1.0, 5.0))
     emit("linear_kernel (AutoRec decoder)", "M=3706 N=6040 K=500", ms, "mfma", 2 * 3706 * 6040 * 500, "2*M*N*K")
+    for tag, fn, flop in (("AutoRec cfg3 x2", lambda: m.reconstruct(X), 2 * 2 * 3706 * 6040 * 500),
+                          ("AutoRec encoder", lambda: ops.linear(X, we, be, "sigmoid", precision="bf16x3"), 2 * 3706 * 6040 * 500),
+                          ("AutoRec encoder, transposed A", lambda: ops.linear(R, we, be, "sigmoid", x_transposed=True, precision="bf16x3"), 2 * 3706 * 6040 * 500),
+                          ("AutoRec decoder", lambda: ops.linear(h, wd, bd, "clamp", 1.0, 5.0, precision="bf16x3"), 2 * 3706 * 6040 * 500)):
+        old = ops.set_tower_precision("bf16x3")
+        ms = timeit(fn)
+        ops.set_tower_precision(old)
+        emit("linear_kernel<SPLIT> bf16x3 (%s)" % tag, "cfg3 shapes", ms, "mfma", flop, "2*M*N*K per GEMM", "fp32-equivalent FLOP/s against the fp32 MFMA peak")
     A = torch.randn(4096, 4096, device=dev); W = torch.randn(4096, 4096, device=dev)
+    ms = timeit(lambda: ops.linear(A, W, precision="bf16x3"), reps=10)
+    emit("linear_kernel<SPLIT> bf16x3 (square)", "M=N=K=4096", ms, "mfma", 2 * 4096 ** 3, "2*M*N*K")
     ms = timeit(lambda: ops.linear(A, W), reps=10)
     emit("linear_kernel (square)", "M=N=K=4096", ms, "mfma", 2 * 4096 ** 3, "2*M*N*K", "guide's untuned LDS-tiled f32-MFMA GEMM: 122 TF")
 
