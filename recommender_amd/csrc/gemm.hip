@@ -110,9 +110,10 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
     // layout: [buf][A tile BM*LS | B tile BN*LS] floats;  split form: [buf][piece(3)][A tile BM*LSB | B tile BN*LSB] bf16
     constexpr int BUF = SPLIT ? 3 * (BM + BN) * LSB / 2 : (BM + BN) * LS;      // in floats
     constexpr int PIECE = (BM + BN) * LSB;                                      // bf16 per piece image
-    // split form: ONE LDS image (61 KB at 128x128), so two workgroups share a CU and one's staging (global loads, operand
-    // splitting, LDS writes) overlaps the other's MFMAs; the exact form double-buffers inside the workgroup instead
-    constexpr int NBUF = SPLIT ? 1 : 2;
+    // split form and transposed A: ONE LDS image, so more workgroups share a CU and one's staging (global loads, operand
+    // splitting / transposing, LDS writes) overlaps the others' MFMAs (measured: transposed encoder 0.30 -> 0.26 ms, split
+    // 4096^3 0.93 -> 0.76 ms); the plain exact form double-buffers inside the workgroup (4096^3: 1.09 vs 1.21 ms single)
+    constexpr int NBUF = (SPLIT || AT) ? 1 : 2;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -305,8 +306,8 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
                             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][ta[term]], fb[tn][tb[term]], acc[tm][tn], 0, 0, 0);
             }
         } else {
-        const float* s_a = smem + (t & 1) * BUF + (wm * (BM / 2) + i) * LS + 4 * h;
-        const float* s_b = smem + (t & 1) * BUF + BM * LS + (wn * (BN / 2) + i) * LS + 4 * h;
+        const float* s_a = smem + (t & (NBUF - 1)) * BUF + (wm * (BM / 2) + i) * LS + 4 * h;
+        const float* s_b = smem + (t & (NBUF - 1)) * BUF + BM * LS + (wn * (BN / 2) + i) * LS + 4 * h;
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {
             f32x4 fa[TM], fb[TN];
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(LinArgs a)
 template <int BM, int BN, int VEC, bool AT, bool SPLIT>
 int launch_v(const LinArgs& a, hipStream_t s)
 {
-    constexpr size_t lds = SPLIT ? (size_t)3 * (BM + BN) * LSB * 2 : (size_t)2 * (BM + BN) * LS * sizeof(float);
+    constexpr size_t lds = SPLIT ? (size_t)3 * (BM + BN) * LSB * 2 : (size_t)(AT ? 1 : 2) * (BM + BN) * LS * sizeof(float);
     static bool attr[RECO_MAX_DEVICES] = {};
     if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&linear_kernel<BM, BN, VEC, AT, SPLIT>), lds, attr)) return rc;
     const int64_t blocks = ceil_div64(a.M, BM) * ceil_div64(a.N, BN) * a.splits;
