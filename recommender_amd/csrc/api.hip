@@ -15,7 +15,7 @@ int tower_launch_tile(int G, int has_l3, const float* img, const float* P, const
                       const float* EUg, const float* EIg, const int64_t* users, const int64_t* cands,
                       int64_t user_base, int64_t n_users, int64_t n_items, int64_t U, int64_t N,
                       float* out, int64_t ld_out, float bp, int act, float lo, float hi, int32_t* oob,
-                      hipStream_t s);
+                      unsigned int* next_tile, hipStream_t s);
 int tower_launch_pairs(int G, int has_l3, const float* img, const float* P, const float* Q,
                        const float* EUg, const float* EIg, const int64_t* user, const int64_t* item,
                        int64_t n_users, int64_t n_items, int64_t B, float* out, float bp, int act,
@@ -27,7 +27,7 @@ int tower_launch_tile_split(int G, int has_l3, const void* img, const float* P, 
                             const float* EUg, const float* EIg, const int64_t* users, const int64_t* cands,
                             int64_t user_base, int64_t n_users, int64_t n_items, int64_t U, int64_t N,
                             float* out, int64_t ld_out, float bp, int act, float lo, float hi, int32_t* oob,
-                            hipStream_t s);
+                            unsigned int* next_tile, hipStream_t s);
 int tower_launch_pairs_split(int G, int has_l3, const void* img, const float* P, const float* Q,
                              const float* EUg, const float* EIg, const int64_t* user, const int64_t* item,
                              int64_t n_users, int64_t n_items, int64_t B, float* out, float bp, int act,
@@ -362,13 +362,14 @@ extern "C" int reco_tower_score_rows(reco_tower_t* t, const float* u_gmf, const 
 }
 
 // ---- matrix / top-k forms ----------------------------------------------------------------------
+static const size_t kQueueBytes = 256;   // tile work-queue counter at the head of the call workspace
 static size_t proj_bytes(int64_t rows) { return align_up((size_t)(rows > 0 ? rows : 0) * H1 * sizeof(float), 256); }
 
-extern "C" size_t reco_tower_matrix_workspace_bytes(int64_t U, int64_t N) { return proj_bytes(U) + proj_bytes(N); }
+extern "C" size_t reco_tower_matrix_workspace_bytes(int64_t U, int64_t N) { return kQueueBytes + proj_bytes(U) + proj_bytes(N); }
 
 static int score_matrix_impl(reco_tower* t, const int64_t* users, int64_t user_base, int64_t U,
                              const int64_t* cands, int64_t N, const float* Qready, float* out, int64_t ld_out,
-                             float* P, float* Q, hipStream_t s)
+                             float* P, float* Q, unsigned int* queue, hipStream_t s)
 {
     const reco_tower_desc_t& d = t->d;
     if (!t->mfma)
@@ -378,13 +379,14 @@ static int score_matrix_impl(reco_tower* t, const int64_t* users, int64_t user_b
     const float* urows = users ? d.user_mlp : d.user_mlp + user_base * d.dm;
     int rc = tower_project(t, urows, users, d.n_users, U, d.item_mlp, cands, d.n_items, Qready ? 0 : N, P, Q, s);
     if (rc) return rc;
+    if (queue) RECO_CHECK_HIP(hipMemsetAsync(queue, 0, sizeof(unsigned int), s));
     ProfScope prof(s);
     if (t->img_split)
         return tower_launch_tile_split(t->G, t->has_l3, t->img_split, P, Qready ? Qready : Q, d.user_gmf, d.item_gmf, users,
                                        cands, user_base, d.n_users, d.n_items, U, N, out, ld_out, t->bp, d.act, d.lo, d.hi,
-                                       t->oob, s);
+                                       t->oob, queue, s);
     return tower_launch_tile(t->G, t->has_l3, t->img, P, Qready ? Qready : Q, d.user_gmf, d.item_gmf, users, cands,
-                             user_base, d.n_users, d.n_items, U, N, out, ld_out, t->bp, d.act, d.lo, d.hi, t->oob, s);
+                             user_base, d.n_users, d.n_items, U, N, out, ld_out, t->bp, d.act, d.lo, d.hi, t->oob, queue, s);
 }
 
 static int check_ranges(const reco_tower* t, const int64_t* users, int64_t user_base, int64_t U, const int64_t* cands,
@@ -409,13 +411,15 @@ extern "C" int reco_tower_score_matrix(reco_tower_t* t, const int64_t* users, in
     int rc = check_ranges(t, users, user_base, U, cands, N, "score_matrix");
     if (rc) return rc;
     float *P = nullptr, *Q = nullptr;
+    unsigned int* queue = nullptr;
     if (t->mfma) {
-        const size_t need = proj_bytes(U) + proj_bytes(N);
+        const size_t need = kQueueBytes + proj_bytes(U) + proj_bytes(N);
         if (!ws || ws_bytes < need) { reco_set_error("score_matrix: workspace too small (%zu < %zu)", ws_bytes, need); return RECO_ENOMEM; }
-        P = static_cast<float*>(ws);
-        Q = reinterpret_cast<float*>(static_cast<char*>(ws) + proj_bytes(U));
+        queue = static_cast<unsigned int*>(ws);
+        P = reinterpret_cast<float*>(static_cast<char*>(ws) + kQueueBytes);
+        Q = reinterpret_cast<float*>(static_cast<char*>(ws) + kQueueBytes + proj_bytes(U));
     }
-    return score_matrix_impl(t, users, user_base, U, cands, N, nullptr, out, ld_out, P, Q, (hipStream_t)stream);
+    return score_matrix_impl(t, users, user_base, U, cands, N, nullptr, out, ld_out, P, Q, queue, (hipStream_t)stream);
 }
 
 // user-chunk size for the fused score + top-k path
@@ -431,7 +435,7 @@ static int64_t default_chunk(int64_t U, int64_t N)
 
 static size_t topk_chunk_bytes(int64_t Uc, int64_t N, int k)
 {
-    return proj_bytes(N) + proj_bytes(Uc) + align_up((size_t)Uc * N * sizeof(float), 256) +
+    return kQueueBytes + proj_bytes(N) + proj_bytes(Uc) + align_up((size_t)Uc * N * sizeof(float), 256) +
            align_up((size_t)(Uc + kTopkExtraRows) * k * sizeof(uint64_t), 256);
 }
 
@@ -466,6 +470,7 @@ extern "C" int reco_tower_score_topk(reco_tower_t* t, const int64_t* users, int6
         return RECO_ENOMEM;
     }
     char* w = static_cast<char*>(ws);
+    unsigned int* queue = t->mfma ? reinterpret_cast<unsigned int*>(w) : nullptr; w += kQueueBytes;
     float* Q = reinterpret_cast<float*>(w); w += proj_bytes(N);
     float* P = reinterpret_cast<float*>(w); w += proj_bytes(Uc);
     float* scores = reinterpret_cast<float*>(w); w += align_up((size_t)Uc * N * sizeof(float), 256);
@@ -479,7 +484,7 @@ extern "C" int reco_tower_score_topk(reco_tower_t* t, const int64_t* users, int6
     }
     for (int64_t c0 = 0; c0 < U; c0 += Uc) {
         const int64_t n = U - c0 < Uc ? U - c0 : Uc;
-        rc = score_matrix_impl(t, users ? users + c0 : nullptr, user_base + c0, n, cands, N, Q, scores, N, P, Q, s);
+        rc = score_matrix_impl(t, users ? users + c0 : nullptr, user_base + c0, n, cands, N, Q, scores, N, P, Q, queue, s);
         if (rc) return rc;
         rc = launch_topk_rows(scores, n, N, N, k, exclude ? exclude + c0 * ld_ex : nullptr, ld_ex, out_ids + c0 * k,
                               out_scores + c0 * k, tws, tws_bytes, s);

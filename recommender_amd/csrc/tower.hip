@@ -185,20 +185,23 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tower_tile_kernel(TileArgs a)
 #ifdef RECO_DIAG_CLOCK
     const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    __shared__ long long s_next[2];
     TileStage<G> st;
     int64_t tile = blockIdx.x;
+    tile_queue_fetch(a, tid, tile + gridDim.x, &s_next[0]);
     if (tile < tiles) {
         tile_stage_load<G>(a, (tile % tiles_n) * TI, tile / tiles_n == 0, tid, st);
         tile_stage_store<G>(s_buf, s_buf + TI * QS, tid, st);
     }
     __syncthreads();
+    int64_t next = s_next[0];
 
-    for (int it = 0; tile < tiles; tile += gridDim.x, ++it) {
+    for (int it = 0; tile < tiles; ++it) {
         const float* s_q = s_buf + (it & 1) * BUF;
         const float* s_g = s_q + TI * QS;
         const int64_t n0 = (tile % tiles_n) * TI;
         const int64_t u0 = (tile / tiles_n) * TUB;
-        const int64_t next = tile + gridDim.x;
+        tile_queue_fetch(a, tid, next + gridDim.x, &s_next[(it + 1) & 1]);     // the tile after next
         if (next < tiles) tile_stage_load<G>(a, (next % tiles_n) * TI, next / tiles_n == 0, tid, st);
 
         for (int uu = wave; uu < TUB; uu += TILE_THREADS / 64) {
@@ -251,6 +254,8 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tower_tile_kernel(TileArgs a)
             tile_stage_store<G>(d_q, d_q + TI * QS, tid, st);
         }
         __syncthreads();   // tile i fully consumed, tile i + 1 fully staged
+        tile = next;
+        next = s_next[(it + 1) & 1];
     }
 #ifdef RECO_DIAG_CLOCK
     if (tid == 0 && (blockIdx.x & 63) == 0) {
@@ -464,10 +469,10 @@ int tower_launch_tile(int G, int has_l3, const float* img, const float* P, const
                       const float* EUg, const float* EIg, const int64_t* users, const int64_t* cands,
                       int64_t user_base, int64_t n_users, int64_t n_items, int64_t U, int64_t N,
                       float* out, int64_t ld_out, float bp, int act, float lo, float hi, int32_t* oob,
-                      hipStream_t s)
+                      unsigned int* next_tile, hipStream_t s)
 {
     if (U <= 0 || N <= 0) return RECO_OK;
-    TileArgs a{img, P, Q, EUg, EIg, users, cands, user_base, n_users, n_items, U, N, out, ld_out, bp, act, lo, hi, oob};
+    TileArgs a{img, P, Q, EUg, EIg, users, cands, user_base, n_users, n_items, U, N, out, ld_out, bp, act, lo, hi, oob, next_tile};
     if (G == 32 && has_l3) return launch_tile_t<32, true>(a, s);
     if (G == 0 && has_l3) return launch_tile_t<0, true>(a, s);
     if (G == 64 && !has_l3) return launch_tile_t<64, false>(a, s);

@@ -94,7 +94,18 @@ struct TileArgs {
     int act;
     float lo, hi;
     int32_t* oob;
+    unsigned int* next_tile;   // work queue: tiles beyond the first gridDim.x are handed out through this counter (zeroed
+                               // before the launch); null = static round-robin
 };
+
+// Tile hand-out for the persistent tile kernels.  Workgroup b starts on tile b; every further tile comes from an atomic
+// counter, so a workgroup slowed down by a co-resident kernel (the RCCL gather of the previous step) or by a ragged
+// tile simply takes fewer tiles.  The index for the tile after next is fetched by thread 0 at the top of an iteration
+// and published through one of two LDS slots behind the iteration's only barrier.
+__device__ __forceinline__ void tile_queue_fetch(const TileArgs& a, int tid, int64_t fallback, long long* slot)
+{
+    if (tid == 0) *slot = a.next_tile ? (long long)gridDim.x + (long long)atomicAdd(a.next_tile, 1u) : (long long)fallback;
+}
 
 template <int G>
 struct TileStage {
