@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from ..dist import packed_topk_buffers
 
 try:
     from fastapi import HTTPException as _Base
@@ -53,7 +54,9 @@ class NCFInferenceEngine:
         self._ready()
         _check_id(user_id, self.config["user_num"], "User", self.model_name)
         _check_id(item_id, self.config["item_num"], "Item", self.model_name)
-        return float(self.model(torch.tensor([user_id]), torch.tensor([item_id])).cpu().item())
+        self.model._check_mode()
+        tower = self.model._tower(self.model._compute_device())              # ids validated above: no range report needed
+        return float(tower.score_pairs(torch.tensor([user_id]), torch.tensor([item_id]), check_ids=False).cpu().item())
 
     def predict_batch(self, user_id, item_ids):
         self._ready()
@@ -63,12 +66,14 @@ class NCFInferenceEngine:
         if not len(item_ids):
             return []
         cands = torch.as_tensor(list(item_ids), dtype=torch.int64)
-        scores = self.model.score_matrix(torch.tensor([user_id]), cands)        # tile path: the user row is projected once
-        order, vals = ops.topk_rows(scores, len(item_ids)) if len(item_ids) <= 128 else (None, None)
-        if order is not None:
-            order = order[0].cpu().numpy(); vals = vals[0].cpu().numpy()
-        else:                                                                  # long lists: stable descending sort on the host
-            sc = scores[0].cpu().numpy()
+        if len(item_ids) <= 128:           # one fused call: the stable descending sort IS the top-n select's order
+            device = self.model._compute_device()
+            buf, ids, vals = packed_topk_buffers(1, len(item_ids), device)
+            self.model.score_topk(torch.tensor([user_id]), len(item_ids), cands, check_ids=False, out=(ids, vals))
+            host = buf.cpu()
+            order = host[0, 0].numpy(); vals = host[1, 0].view(torch.float32).numpy()
+        else:                              # long lists: tile path + stable descending sort on the host
+            sc = self.model.score_matrix(torch.tensor([user_id]), cands)[0].cpu().numpy()
             order = np.argsort(-sc, kind="stable"); vals = sc[order]
         return [(int(item_ids[j]), float(v)) for j, v in zip(order, vals)]
 
@@ -87,8 +92,12 @@ class NCFInferenceEngine:
             cands = torch.as_tensor(uniq, dtype=torch.int64)
             n = len(uniq)
         k = min(k, n)
-        ids, vals = self.model.score_topk(torch.tensor([user_id]), k, cands)
-        ids = ids[0].cpu().numpy(); vals = vals[0].cpu().numpy()
+        # ids were validated above, so the kernel-side range report (a sync) is skipped; ids and scores come back in ONE copy
+        device = self.model._compute_device()
+        buf, ids, vals = packed_topk_buffers(1, k, device)
+        self.model.score_topk(torch.tensor([user_id]), k, cands, check_ids=False, out=(ids, vals))
+        host = buf.cpu()
+        ids = host[0, 0].numpy(); vals = host[1, 0].view(torch.float32).numpy()
         if cands is not None:
             ids = cands.numpy()[ids]
         return [(int(i), float(v)) for i, v in zip(ids, vals)]

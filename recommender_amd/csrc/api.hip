@@ -424,6 +424,7 @@ extern "C" int reco_tower_score_matrix(reco_tower_t* t, const int64_t* users, in
 
 // user-chunk size for the fused score + top-k path
 static const size_t kScoreChunkBytes = (size_t)1 << 30;   // ~1 GiB of score rows per chunk
+static const int64_t kServingUsers = 16;                  // at most this many users: a request, not a batch job
 static const int64_t kTopkExtraRows = 8192;               // bound of rows*splits - rows in topk.hip choose_splits
 
 static int64_t default_chunk(int64_t U, int64_t N)
@@ -478,7 +479,11 @@ extern "C" int reco_tower_score_topk(reco_tower_t* t, const int64_t* users, int6
     const size_t tws_bytes = align_up((size_t)(Uc + kTopkExtraRows) * k * sizeof(uint64_t), 256);
 
     const reco_tower_desc_t& d = t->d;
-    if (t->mfma) {   // item-side projection once per call
+    // item-side projection once per call.  Request-sized calls over the whole catalog (a handful of users: the serving
+    // path, inference_engine.py:149-166) reuse the projection of all items that the handle packed at creation instead.
+    const bool cached_q = t->mfma && !cands && N == d.n_items && U <= kServingUsers && t->Q;
+    if (cached_q) Q = t->Q;
+    else if (t->mfma) {
         rc = tower_project(t, nullptr, nullptr, 0, 0, d.item_mlp, cands, d.n_items, N, nullptr, Q, s);
         if (rc) return rc;
     }

@@ -164,12 +164,13 @@ class NCF(nn.Module):
         device = self._compute_device(users, candidates)
         return self._tower(device).score_matrix(users, candidates)
 
-    def score_topk(self, users=None, k=10, candidates=None, exclude=None):
+    def score_topk(self, users=None, k=10, candidates=None, exclude=None, check_ids=True, out=None):
         """Per-user top-k over the candidates: (ids int32 [U,k], scores float32 [U,k]) on the GPU.
 
         ids index into `candidates` (they are item ids when candidates is None).  Replaces the
         model(...) + np.argsort(...)[::-1][:k] pair of inference_engine.py:162-166.
+        check_ids=False skips the out-of-range report (one device-to-host sync) for callers that validated the ids.
         """
         self._check_mode()
         device = self._compute_device(users, candidates)
-        return self._tower(device).score_topk(users, k, candidates, exclude)
+        return self._tower(device).score_topk(users, k, candidates, exclude, check_ids=check_ids, out=out)
