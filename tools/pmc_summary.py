@@ -2,9 +2,9 @@
 """Per-kernel averages of rocprofv3 --pmc passes -> one JSON (the file bench.py reads `roofline.traffic` from).
 
     cd /tmp && export TMPDIR=/tmp
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d OUT/fetch -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-cfg5
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d OUT/fetch -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d OUT/write -- python3 bench.py ...          (separate pass: TCC has 4 slots)
-    rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CU_CYCLES -d OUT/mfma -- ...
+    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES -d OUT/mfma -- ...
     python tools/pmc_summary.py OUT/fetch OUT/write OUT/mfma > profiles/rNN_bench_n1_hbm_traffic.json
 
 Corrections (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
