@@ -169,8 +169,13 @@ def topk_rows(scores, k, exclude=None):
 
     exclude (bool/uint8 [rows,N]) applies helper.py:313 (score*(~seen) - seen*1e10) before the select.
     """
-    scores = _f32(scores, "scores", 2)
+    if isinstance(scores, torch.Tensor) and scores.dim() == 2 and scores.is_cuda and scores.dtype == torch.float32 \
+            and scores.stride(1) == 1 and scores.stride(0) >= scores.shape[1]:
+        pass                                        # a column block of a wider row-major buffer is read in place: ld = stride(0)
+    else:
+        scores = _f32(scores, "scores", 2)
     rows, N = scores.shape
+    ld = scores.stride(0) if rows > 1 else N
     if exclude is not None:
         exclude = _mask(exclude, scores)
     ids = torch.empty((rows, k), dtype=torch.int32, device=scores.device)
@@ -179,7 +184,7 @@ def topk_rows(scores, k, exclude=None):
     nbytes = L.reco_topk_workspace_bytes(rows, N, k)
     ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=scores.device)
     with torch.cuda.device(scores.device):
-        check(L.reco_topk_rows(_p(scores), rows, N, N, k, _p(exclude), N, _p(ids), _p(vals), _p(ws), nbytes,
+        check(L.reco_topk_rows(_p(scores), rows, N, ld, k, _p(exclude), N, _p(ids), _p(vals), _p(ws), nbytes,
                                _stream(scores.device)))
     return ids, vals
 

@@ -273,3 +273,46 @@ def test_linear_shapes_and_epilogues(tower_precision):
         y2 = ops.linear(torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda(), torch.from_numpy(bm).cuda(), bias_per_row=True)
         err = np.abs(y2.cpu().numpy() - (x.astype(np.float64) @ w.astype(np.float64).T + bm[:, None]))
         assert (err <= 4e-7 * (scale + 1) + 1e-6).all(), (M, N, K, "bias_per_row")
+
+
+def test_linear_random_shape_sweep(tower_precision):
+    """Seeded sweep over ragged shapes and alignments (K odd -> 4-byte loads, K even -> 8-byte, strided A / C views)."""
+    from recommender_amd import ops
+    rng = np.random.default_rng(2026)
+    for case in range(36):
+        M = int(rng.integers(1, 400)); N = int(rng.integers(1, 300))
+        K = int(rng.choice([rng.integers(1, 64), rng.integers(64, 700), rng.integers(1024, 3000)]))
+        x = rng.standard_normal((M, K + 5)).astype(np.float32); w = rng.standard_normal((N, K)).astype(np.float32)
+        b = rng.standard_normal(N).astype(np.float32)
+        xg = torch.from_numpy(x).cuda()[:, 3:3 + K] if case % 3 == 0 else torch.from_numpy(np.ascontiguousarray(x[:, 3:3 + K])).cuda()
+        out = torch.full((M, N + 4), 7.0, device="cuda")[:, :N] if case % 4 == 1 else None
+        y = ops.linear(xg, torch.from_numpy(w).cuda(), torch.from_numpy(b).cuda(), "relu", out=out)
+        xs = x[:, 3:3 + K].astype(np.float64)
+        ref = np.maximum(xs @ w.astype(np.float64).T + b, 0)
+        scale = np.abs(xs) @ np.abs(w).astype(np.float64).T + np.abs(b)
+        err = np.abs(y.cpu().numpy() - ref)
+        assert (err <= 4e-7 * scale + 1e-6).all(), (case, M, N, K, err.max())
+        if out is not None:
+            assert y.data_ptr() == out.data_ptr()
+
+
+def test_topk_random_sweep():
+    """Seeded sweep: row lengths around the vector-load switch (1024), k around the one/two-slot switch (64), row views with
+    a leading dimension larger than N, masks, heavy ties."""
+    from recommender_amd import ops
+    rng = np.random.default_rng(77)
+    for case in range(40):
+        rows = int(rng.integers(1, 40))
+        N = int(rng.choice([rng.integers(1, 130), rng.integers(1000, 1100), rng.integers(4000, 9000), 4096, 1024]))
+        k = int(min(N, rng.choice([1, 5, 10, 63, 64, 65, 100, 128])))
+        ld = N + int(rng.choice([0, 0, 1, 3, 4]))
+        full = rng.standard_normal((rows, ld)).astype(np.float32)
+        if case % 3 == 0:
+            full = np.round(full * 2) / 2                       # many equal scores
+        t = torch.from_numpy(full).cuda()[:, :N]
+        sc = full[:, :N]
+        ex = rng.random((rows, N)) < rng.choice([0.0, 0.3, 0.95])
+        ids, vals = ops.topk_rows(t, k, torch.from_numpy(ex).cuda() if case % 2 else None)
+        oid, oval = O.topk_rows(O.mask_seen(sc, ex) if case % 2 else sc, k)
+        assert np.array_equal(ids.cpu().numpy(), oid), (case, rows, N, k, ld)
+        assert np.array_equal(vals.cpu().numpy(), oval), (case, rows, N, k, ld)
