@@ -21,7 +21,8 @@ __device__ __forceinline__ int64_t clamp_row(int64_t id, int64_t n, int32_t* oob
     return id;
 }
 
-__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, int64_t rows, int dim4,
+template <bool POW2>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, int64_t rows, int dim4, int sh,
                                                           const int64_t* __restrict__ idx, int64_t B,
                                                           float* __restrict__ out, int32_t* oob)
 {
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int64_t t = t0 + u * stride;
-            const int64_t b = t < total ? t / dim4 : 0;
+            const int64_t b = t < total ? (POW2 ? t >> sh : t / dim4) : 0;
             c[u] = (int)((t < total ? t : 0) - b * dim4);
             r[u] = t < total ? clamp_row(idx[b], rows, oob, c[u] == 0) : 0;
         }
@@ -64,7 +65,10 @@ struct FusedArgs {
 
 // per pair: g4 float4 of gmf product + 2*m4 float4 of [user | item] MLP rows; work items are laid
 // out so that consecutive lanes write consecutive float4 of the outputs.
-__global__ __launch_bounds__(256) void neumf_gather_kernel(FusedArgs a)
+// POW2: both row widths are powers of two (the shipped 32 / 128): pair and column come from a shift and a mask instead
+// of a 64-bit division per float4 -- at 5 TB/s the index arithmetic is otherwise a visible share of the kernel.
+template <bool POW2>
+__global__ __launch_bounds__(256) void neumf_gather_kernel(FusedArgs a, int sh_m, int sh_g)
 {
     constexpr int UNROLL = 4;
     const int64_t stride = (int64_t)gridDim.x * 256;
@@ -78,8 +82,8 @@ __global__ __launch_bounds__(256) void neumf_gather_kernel(FusedArgs a)
             for (int u = 0; u < UNROLL; ++u) {
                 const int64_t t = t0 + u * stride;
                 const bool ok = t < total;
-                const int64_t b = ok ? t / per_pair : 0;
-                const int c = ok ? (int)(t - b * per_pair) : 0;
+                const int64_t b = ok ? (POW2 ? t >> sh_m : t / per_pair) : 0;
+                const int c = ok ? (POW2 ? (int)(t & (per_pair - 1)) : (int)(t - b * per_pair)) : 0;
                 dst[u] = ok ? b * a.ldm4 + c : -1;
                 if (c < a.m4) src[u] = reinterpret_cast<const f32x4*>(a.Eu_m) + clamp_row(a.user[b], a.n_users, a.oob, ok && c == 0) * a.m4 + c;
                 else src[u] = reinterpret_cast<const f32x4*>(a.Ei_m) + clamp_row(a.item[b], a.n_items, a.oob, ok && c == a.m4) * a.m4 + (c - a.m4);
@@ -101,8 +105,8 @@ __global__ __launch_bounds__(256) void neumf_gather_kernel(FusedArgs a)
             for (int u = 0; u < UNROLL; ++u) {
                 const int64_t t = t0 + u * stride;
                 const bool ok = t < total;
-                const int64_t b = ok ? t / a.g4 : 0;
-                const int c = ok ? (int)(t - b * a.g4) : 0;
+                const int64_t b = ok ? (POW2 ? t >> sh_g : t / a.g4) : 0;
+                const int c = ok ? (POW2 ? (int)(t & (a.g4 - 1)) : (int)(t - b * a.g4)) : 0;
                 dst[u] = ok ? b * a.ldg4 + c : -1;
                 su[u] = reinterpret_cast<const f32x4*>(a.Eu_g) + clamp_row(a.user[b], a.n_users, a.oob, ok && c == 0 && !a.mlp_in) * a.g4 + c;
                 si[u] = reinterpret_cast<const f32x4*>(a.Ei_g) + clamp_row(a.item[b], a.n_items, a.oob, ok && c == 0 && !a.mlp_in) * a.g4 + c;
@@ -115,6 +119,13 @@ __global__ __launch_bounds__(256) void neumf_gather_kernel(FusedArgs a)
                 if (dst[u] >= 0) __builtin_nontemporal_store(vu[u] * vi[u], reinterpret_cast<f32x4*>(a.gmf_prod) + dst[u]);
         }
     }
+}
+
+static int log2_exact(int v)
+{
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return (v > 0 && (1 << s) == v) ? s : -1;
 }
 
 unsigned stream_grid(int64_t work_items)
@@ -132,8 +143,13 @@ extern "C" int reco_gather_rows(const float* table, int64_t rows, int dim, const
     RECO_REQUIRE(table && idx && out, "gather_rows: null pointer");
     RECO_REQUIRE(dim > 0 && dim % 4 == 0, "gather_rows: dim must be a positive multiple of 4, got %d", dim);
     RECO_REQUIRE(rows > 0, "gather_rows: empty table");
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(stream_grid(B * (dim / 4))), dim3(256), 0, (hipStream_t)stream,
-                       table, rows, dim / 4, idx, B, out, oob);
+    const int sh = log2_exact(dim / 4);
+    if (sh >= 0)
+        hipLaunchKernelGGL(gather_rows_kernel<true>, dim3(stream_grid(B * (dim / 4))), dim3(256), 0, (hipStream_t)stream,
+                           table, rows, dim / 4, sh, idx, B, out, oob);
+    else
+        hipLaunchKernelGGL(gather_rows_kernel<false>, dim3(stream_grid(B * (dim / 4))), dim3(256), 0, (hipStream_t)stream,
+                           table, rows, dim / 4, 0, idx, B, out, oob);
     RECO_CHECK_LAUNCH();
     return RECO_OK;
 }
@@ -156,7 +172,11 @@ extern "C" int reco_neumf_gather(const float* Eu_g, const float* Ei_g, const flo
     RECO_REQUIRE((uintptr_t)gmf_prod % 16 == 0 && (uintptr_t)mlp_in % 16 == 0, "neumf_gather: outputs must be 16-byte aligned");
     FusedArgs a{Eu_g, Ei_g, Eu_m, Ei_m, n_users, n_items, dg / 4, dm / 4, user, item, B, gmf_prod, mlp_in, ld_gmf / 4, ld_mlp / 4, oob};
     const int64_t work = B * (mlp_in ? 2 * (dm / 4) : dg / 4);
-    hipLaunchKernelGGL(neumf_gather_kernel, dim3(stream_grid(work)), dim3(256), 0, (hipStream_t)stream, a);
+    const int sh_m = mlp_in ? log2_exact(2 * (dm / 4)) : 0, sh_g = gmf_prod ? log2_exact(dg / 4) : 0;
+    if (sh_m >= 0 && sh_g >= 0)
+        hipLaunchKernelGGL(neumf_gather_kernel<true>, dim3(stream_grid(work)), dim3(256), 0, (hipStream_t)stream, a, sh_m, sh_g);
+    else
+        hipLaunchKernelGGL(neumf_gather_kernel<false>, dim3(stream_grid(work)), dim3(256), 0, (hipStream_t)stream, a, 0, 0);
     RECO_CHECK_LAUNCH();
     return RECO_OK;
 }
