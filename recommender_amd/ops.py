@@ -132,6 +132,8 @@ def linear(x, weight, bias=None, act=None, lo=0.0, hi=0.0, out=None, x_transpose
     nbytes = L.reco_linear_workspace_bytes(M, N, K)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
     lda = x.stride(0) if x.shape[0] > 1 else x.shape[1]
+    if precision is not None and precision not in PRECISIONS:
+        raise ValueError("precision must be one of %s, got %r" % (sorted(PRECISIONS), precision))
     flags = (1 if x_transposed else 0) | (2 if bias_per_row else 0) | (4 if PRECISIONS[precision or tower_precision()] else 0)
     with torch.cuda.device(x.device):
         check(L.reco_linear_f32(_p(x), lda, None, 0, M, _p(weight), K, _p(bias), N, K, ACTS[act], lo, hi,
@@ -234,6 +236,8 @@ class Tower:
                  dg=None, dm=None, act=None, lo=1.0, hi=5.0, precision=None):
         require_gpu()
         self.precision = precision or tower_precision()
+        if self.precision not in PRECISIONS:
+            raise ValueError("precision must be one of %s, got %r" % (sorted(PRECISIONS), self.precision))
         dev = w_predict.device
         self.device = dev
         keep = []

@@ -113,3 +113,45 @@ def test_autorec_and_hybrid_ranking_evaluators(g3, g4, tower_precision):
     users = [u for u in range(40) if test[u].any()]
     ohr = np.mean([O.hit_multi(np.flatnonzero(test[u] > 0), oid[u]) for u in users])
     assert abs(hr - ohr) <= 1.0 / len(users)
+
+
+def test_c_abi_rejects_bad_arguments_with_error_codes_not_faults():
+    """Straight through ctypes: every refused call returns a negative code and leaves a message, nothing is launched."""
+    import ctypes
+    from recommender_amd import _lib, ops
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.randn(8, 16, device=dev); w = torch.randn(4, 16, device=dev); y = torch.empty(8, 4, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+
+    def refused(rc, code, fragment):
+        assert rc == code, rc
+        assert fragment in L.reco_last_error().decode(), L.reco_last_error()
+
+    refused(L.reco_linear_f32(None, 16, None, 0, 8, p(w), 16, None, 4, 16, 0, 0.0, 0.0, p(y), 4, 0, None, 0, st), _lib.EINVAL, "null")
+    refused(L.reco_linear_f32(p(x), 8, None, 0, 8, p(w), 16, None, 4, 16, 0, 0.0, 0.0, p(y), 4, 0, None, 0, st), _lib.EINVAL, "leading dimension")
+    refused(L.reco_linear_f32(p(x), 16, None, 0, 8, p(w), 16, None, 4, 16, 99, 0.0, 0.0, p(y), 4, 0, None, 0, st), _lib.EINVAL, "activation")
+    refused(L.reco_linear_f32(p(x), 16, None, 0, 8, p(w), 16, None, 4, 16, 0, 0.0, 0.0, p(y), 4, 64, None, 0, st), _lib.EINVAL, "flags")
+    ids = torch.empty(8, 3, dtype=torch.int32, device=dev); vals = torch.empty(8, 3, device=dev)
+    refused(L.reco_topk_rows(p(x), 8, 16, 16, 0, None, 0, p(ids), p(vals), None, 0, st), _lib.EINVAL, "k must be")
+    refused(L.reco_topk_rows(p(x), 8, 16, 16, 17, None, 0, p(ids), p(vals), None, 0, st), _lib.EINVAL, "exceeds")
+    refused(L.reco_topk_rows(p(x), 8, 16, 8, 3, None, 0, p(ids), p(vals), None, 0, st), _lib.EINVAL, "ld smaller")
+    idx = torch.zeros(4, dtype=torch.int64, device=dev)
+    refused(L.reco_gather_rows(p(x), 8, 6, p(idx), 4, p(y), None, st), _lib.EINVAL, "multiple of 4")
+
+    d = _lib.TowerDesc()                                     # a tower with no branch at all
+    h = ctypes.c_void_p()
+    refused(L.reco_tower_create(ctypes.byref(d), st, ctypes.byref(h)), _lib.EINVAL, "neither")
+    assert not h.value
+    # a real handle: too small a workspace is ENOMEM, an unknown precision EINVAL
+    from recommender_amd.helpers import NCF
+    torch.manual_seed(0)
+    t = NCF(40, 30, 32, 3, 0.0, "NeuMF-end").eval().cuda()._tower(dev)
+    out = torch.empty(40, 30, device=dev)
+    refused(L.reco_tower_score_matrix(t._h, None, 0, 40, None, 30, p(out), 30, None, 0, st), _lib.ENOMEM, "workspace")
+    refused(L.reco_tower_score_matrix(t._h, None, 35, 10, None, 30, p(out), 30, None, 0, st), _lib.EINVAL, "user range")
+    refused(L.reco_tower_score_pairs(None, None, None, 4, None, st), _lib.EINVAL, "null handle")
+    with pytest.raises(ValueError):
+        ops.Tower(w_predict=torch.zeros(64, device=dev), b_predict=torch.zeros(1, device=dev), precision="fp8")
+    torch.cuda.synchronize()
