@@ -93,12 +93,14 @@ __device__ __forceinline__ float tower_mlp_part(const float* s_img, int lane, X1
     const f32x4* w2 = reinterpret_cast<const f32x4*>(s_img + IMG_W2) + lane;
     // software-pipelined by one quad: the LDS reads (and the add+ReLU) of quad q+1 are issued ahead of
     // the 8 MFMAs of quad q, so no MFMA waits on an LDS round trip
-    f32x4 x = x1.finish(0, x1.raw(0));
+    auto r0 = x1.raw(0);
+    f32x4 x = x1.finish(0, r0);
     f32x4 a0 = w2[0];
     f32x4 a1 = w2[16 * 64];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        f32x4 xraw = x, a0n = a0, a1n = a1;
+        auto xraw = r0;                         // (type only: overwritten below whenever it is used)
+        f32x4 a0n = a0, a1n = a1;
         if (q + 1 < 16) {                       // issue quad q+1's three ds_read_b128 first ...
             xraw = x1.raw(q + 1);
 #ifndef RECO_ABL_NO_W2_READS
@@ -114,7 +116,7 @@ __device__ __forceinline__ float tower_mlp_part(const float* s_img, int lane, X1
         __builtin_amdgcn_sched_barrier(0);
         f32x4 xn = x;
 #ifdef RECO_ABL_NO_X1_VALU
-        if (q + 1 < 16) xn = xraw;
+        if (q + 1 < 16) xn = x1.passthrough(xraw);
 #else
         if (q + 1 < 16) xn = x1.finish(q + 1, xraw);   // ... their data is back 4 MFMAs (256 cycles) later
 #endif
@@ -162,6 +164,8 @@ __device__ __forceinline__ float tower_mlp_part(const float* s_img, int lane, X1
     return part;
 }
 
+constexpr bool tile_plds(int g) { return g <= 32; }     // the Hybrid head's 64-wide GMF tile leaves no room for a P tile
+
 template <int G, bool L3>
 __global__ __launch_bounds__(TILE_THREADS, 2) void tower_tile_kernel(TileArgs a)
 {
@@ -170,6 +174,11 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tower_tile_kernel(TileArgs a)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_img = smem;
     float* s_buf = smem + IMG_SIZE;
+    // P rows of the tile's users: staged in LDS with the item side when it fits (G <= 32), read per quad by a broadcast
+    // ds_read_b128 instead of living in 64 VGPRs that a global load has to refill at every user switch
+    constexpr bool PLDS = tile_plds(G);
+    constexpr int NP = TUB * (H1 / 4) / TILE_THREADS;          // float4 of P per thread (2)
+    float* s_pbuf = s_buf + 2 * BUF;                            // [2][TUB][H1]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -182,6 +191,27 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tower_tile_kernel(TileArgs a)
     for (int i = tid; i < IMG_SIZE / 4; i += TILE_THREADS)
         reinterpret_cast<f32x4*>(s_img)[i] = reinterpret_cast<const f32x4*>(a.img)[i];
 
+    f32x4 pst[PLDS ? NP : 1];
+    auto p_stage_load = [&](int64_t t) {
+        if constexpr (PLDS) {
+            const int64_t ub = (t / tiles_n) * TUB;
+#pragma unroll
+            for (int s = 0; s < NP; ++s) {
+                const int i = tid + s * TILE_THREADS;
+                const int64_t u = ub + (i >> 5);
+                pst[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (u < a.U) pst[s] = reinterpret_cast<const f32x4*>(a.P + u * H1)[i & 31];
+            }
+        }
+    };
+    auto p_stage_store = [&](int buf) {
+        if constexpr (PLDS) {
+#pragma unroll
+            for (int s = 0; s < NP; ++s)
+                reinterpret_cast<f32x4*>(s_pbuf + buf * TUB * H1)[tid + s * TILE_THREADS] = pst[s];
+        }
+    };
+
 #ifdef RECO_DIAG_CLOCK
     const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -192,6 +222,8 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tower_tile_kernel(TileArgs a)
     if (tile < tiles) {
         tile_stage_load<G>(a, (tile % tiles_n) * TI, tile / tiles_n == 0, tid, st);
         tile_stage_store<G>(s_buf, s_buf + TI * QS, tid, st);
+        p_stage_load(tile);
+        p_stage_store(0);
     }
     __syncthreads();
     int64_t next = s_next[0];
@@ -202,15 +234,18 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tower_tile_kernel(TileArgs a)
         const int64_t n0 = (tile % tiles_n) * TI;
         const int64_t u0 = (tile / tiles_n) * TUB;
         tile_queue_fetch(a, tid, next + gridDim.x, &s_next[(it + 1) & 1]);     // the tile after next
-        if (next < tiles) tile_stage_load<G>(a, (next % tiles_n) * TI, next / tiles_n == 0, tid, st);
+        if (next < tiles) { tile_stage_load<G>(a, (next % tiles_n) * TI, next / tiles_n == 0, tid, st); p_stage_load(next); }
+        const float* s_p = s_pbuf + (it & 1) * TUB * H1;
 
         for (int uu = wave; uu < TUB; uu += TILE_THREADS / 64) {
             const int64_t u = u0 + uu;
             if (u >= a.U) break;
-            f32x4 p[16];
-            const f32x4* prow = reinterpret_cast<const f32x4*>(a.P + u * H1 + 4 * h);
+            f32x4 p[PLDS ? 1 : 16];
+            if constexpr (!PLDS) {
+                const f32x4* prow = reinterpret_cast<const f32x4*>(a.P + u * H1 + 4 * h);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) p[q] = prow[2 * q];
+                for (int q = 0; q < 16; ++q) p[q] = prow[2 * q];
+            }
             f32x4 gu[G > 0 ? G / 8 : 1];
             if constexpr (G > 0) {
                 const int64_t uid = clamp_id(a.users ? a.users[u] : a.user_base + u, a.n_users,
@@ -231,8 +266,22 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tower_tile_kernel(TileArgs a)
                     const f32x4* p;
                     __device__ __forceinline__ f32x4 raw(int q) const { return *reinterpret_cast<const f32x4*>(qrow + 8 * q); }
                     __device__ __forceinline__ f32x4 finish(int q, f32x4 v) const { return relu4(p[q] + v); }
+                    __device__ __forceinline__ f32x4 passthrough(f32x4 v) const { return v; }
                 };
-                float part = tower_mlp_part<L3>(s_img, lane, X1Tile{qrow, p});
+                struct PQ { f32x4 q, p; };
+                struct X1TileLds {
+                    const float* qrow;
+                    const float* prow;     // this user's P row in LDS (+ 4 h)
+                    __device__ __forceinline__ PQ raw(int q) const
+                    {
+                        return PQ{*reinterpret_cast<const f32x4*>(qrow + 8 * q), *reinterpret_cast<const f32x4*>(prow + 8 * q)};
+                    }
+                    __device__ __forceinline__ f32x4 finish(int, const PQ& v) const { return relu4(v.p + v.q); }
+                    __device__ __forceinline__ f32x4 passthrough(const PQ& v) const { return v.q; }
+                };
+                float part;
+                if constexpr (PLDS) part = tower_mlp_part<L3>(s_img, lane, X1TileLds{qrow, s_p + uu * H1 + 4 * h});
+                else part = tower_mlp_part<L3>(s_img, lane, X1Tile{qrow, p});
                 if constexpr (G > 0) {
                     const float* grow = s_g + (g * 32 + j) * GS + h * (G / 2);
 #pragma unroll
@@ -252,6 +301,7 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tower_tile_kernel(TileArgs a)
         if (next < tiles) {
             float* d_q = s_buf + ((it + 1) & 1) * BUF;
             tile_stage_store<G>(d_q, d_q + TI * QS, tid, st);
+            p_stage_store((it + 1) & 1);
         }
         __syncthreads();   // tile i fully consumed, tile i + 1 fully staged
         tile = next;
@@ -299,6 +349,7 @@ __global__ __launch_bounds__(256, 1) void tower_pairs_kernel(PairArgs a)
             const float* xrow;
             __device__ __forceinline__ f32x4 raw(int q) const { return *reinterpret_cast<const f32x4*>(xrow + 8 * q); }
             __device__ __forceinline__ f32x4 finish(int, f32x4 v) const { return v; }
+            __device__ __forceinline__ f32x4 passthrough(f32x4 v) const { return v; }
         };
         float part = tower_mlp_part<L3>(s_img, lane, X1Pair{xrow});
         if constexpr (G > 0) {
@@ -420,7 +471,7 @@ __global__ __launch_bounds__(256) void gmf_tile_kernel(GmfTileArgs a)
 template <int G, bool L3>
 int launch_tile_t(const TileArgs& a, hipStream_t s)
 {
-    constexpr size_t lds = (size_t)(IMG_SIZE + 2 * (TI * QS + (G > 0 ? TI * (G + 4) : 0))) * sizeof(float);
+    constexpr size_t lds = (size_t)(IMG_SIZE + 2 * (TI * QS + (G > 0 ? TI * (G + 4) : 0)) + (tile_plds(G) ? 2 * TUB * H1 : 0)) * sizeof(float);
     static_assert(lds <= 160 * 1024, "tile kernel LDS budget");
     static bool attr[RECO_MAX_DEVICES] = {};
     if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&tower_tile_kernel<G, L3>), lds, attr)) return rc;
