@@ -166,9 +166,13 @@ __device__ __forceinline__ float tower_mlp_part(const float* s_img, int lane, X1
 
 constexpr bool tile_plds(int g) { return g <= 32; }     // the Hybrid head's 64-wide GMF tile leaves no room for a P tile
 
-template <int G, bool L3>
-__global__ __launch_bounds__(TILE_THREADS, 2) void tower_tile_kernel(TileArgs a)
+// THREADS / TUBX: 512 threads x 32 users per tile (2 waves per SIMD), or, once the P rows live in LDS and the kernel needs
+// <= 170 VGPRs, 768 threads x 24 users (3 waves per SIMD).
+template <int G, bool L3, int THREADS, int TUBX>
+__global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(TileArgs a)
 {
+    constexpr int TILE_THREADS = THREADS;      // shadow the 512-thread defaults of tower_shared.h
+    constexpr int TUB = TUBX;
     constexpr int GS = G + 4;
     constexpr int BUF = TI * QS + (G > 0 ? TI * GS : 0);      // floats per item-side buffer
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tower_tile_kernel(TileArgs a)
     // P rows of the tile's users: staged in LDS with the item side when it fits (G <= 32), read per quad by a broadcast
     // ds_read_b128 instead of living in 64 VGPRs that a global load has to refill at every user switch
     constexpr bool PLDS = tile_plds(G);
-    constexpr int NP = TUB * (H1 / 4) / TILE_THREADS;          // float4 of P per thread (2)
+    constexpr int NP = (TUB * (H1 / 4) + TILE_THREADS - 1) / TILE_THREADS;   // float4 of P per thread (2; 1 at 768 x 24)
     float* s_pbuf = s_buf + 2 * BUF;                            // [2][TUB][H1]
 
     const int tid = threadIdx.x;
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tower_tile_kernel(TileArgs a)
                 const int i = tid + s * TILE_THREADS;
                 const int64_t u = ub + (i >> 5);
                 pst[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (u < a.U) pst[s] = reinterpret_cast<const f32x4*>(a.P + u * H1)[i & 31];
+                if (i < TUB * (H1 / 4) && u < a.U) pst[s] = reinterpret_cast<const f32x4*>(a.P + u * H1)[i & 31];
             }
         }
     };
@@ -208,7 +212,8 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tower_tile_kernel(TileArgs a)
         if constexpr (PLDS) {
 #pragma unroll
             for (int s = 0; s < NP; ++s)
-                reinterpret_cast<f32x4*>(s_pbuf + buf * TUB * H1)[tid + s * TILE_THREADS] = pst[s];
+                if (tid + s * TILE_THREADS < TUB * (H1 / 4))
+                    reinterpret_cast<f32x4*>(s_pbuf + buf * TUB * H1)[tid + s * TILE_THREADS] = pst[s];
         }
     };
 
@@ -216,12 +221,12 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tower_tile_kernel(TileArgs a)
     const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     __shared__ long long s_next[2];
-    TileStage<G> st;
+    TileStage<G, THREADS> st;
     int64_t tile = blockIdx.x;
     tile_queue_fetch(a, tid, tile + gridDim.x, &s_next[0]);
     if (tile < tiles) {
-        tile_stage_load<G>(a, (tile % tiles_n) * TI, tile / tiles_n == 0, tid, st);
-        tile_stage_store<G>(s_buf, s_buf + TI * QS, tid, st);
+        tile_stage_load<G, THREADS>(a, (tile % tiles_n) * TI, tile / tiles_n == 0, tid, st);
+        tile_stage_store<G, THREADS>(s_buf, s_buf + TI * QS, tid, st);
         p_stage_load(tile);
         p_stage_store(0);
     }
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tower_tile_kernel(TileArgs a)
         const int64_t n0 = (tile % tiles_n) * TI;
         const int64_t u0 = (tile / tiles_n) * TUB;
         tile_queue_fetch(a, tid, next + gridDim.x, &s_next[(it + 1) & 1]);     // the tile after next
-        if (next < tiles) { tile_stage_load<G>(a, (next % tiles_n) * TI, next / tiles_n == 0, tid, st); p_stage_load(next); }
+        if (next < tiles) { tile_stage_load<G, THREADS>(a, (next % tiles_n) * TI, next / tiles_n == 0, tid, st); p_stage_load(next); }
         const float* s_p = s_pbuf + (it & 1) * TUB * H1;
 
         for (int uu = wave; uu < TUB; uu += TILE_THREADS / 64) {
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tower_tile_kernel(TileArgs a)
         }
         if (next < tiles) {
             float* d_q = s_buf + ((it + 1) & 1) * BUF;
-            tile_stage_store<G>(d_q, d_q + TI * QS, tid, st);
+            tile_stage_store<G, THREADS>(d_q, d_q + TI * QS, tid, st);
             p_stage_store((it + 1) & 1);
         }
         __syncthreads();   // tile i fully consumed, tile i + 1 fully staged
@@ -471,10 +476,13 @@ __global__ __launch_bounds__(256) void gmf_tile_kernel(GmfTileArgs a)
 template <int G, bool L3>
 int launch_tile_t(const TileArgs& a, hipStream_t s)
 {
-    constexpr size_t lds = (size_t)(IMG_SIZE + 2 * (TI * QS + (G > 0 ? TI * (G + 4) : 0)) + (tile_plds(G) ? 2 * TUB * H1 : 0)) * sizeof(float);
+    // with the P rows in LDS the kernel needs 143 VGPRs: three waves per SIMD (768 threads, 24 users per tile, LDS 152 KB)
+    // measured 3.35 -> 3.32 ms; the Hybrid head keeps 512 threads x 32 users (P rows in registers)
+    constexpr int THREADS = tile_plds(G) ? 768 : 512, TUBX = tile_plds(G) ? 24 : TUB;
+    constexpr size_t lds = (size_t)(IMG_SIZE + 2 * (TI * QS + (G > 0 ? TI * (G + 4) : 0)) + (tile_plds(G) ? 2 * TUBX * H1 : 0)) * sizeof(float);
     static_assert(lds <= 160 * 1024, "tile kernel LDS budget");
     static bool attr[RECO_MAX_DEVICES] = {};
-    if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&tower_tile_kernel<G, L3>), lds, attr)) return rc;
+    if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&tower_tile_kernel<G, L3, THREADS, TUBX>), lds, attr)) return rc;
     static int n_cu = 0;                                  // one GPU model per node: the CU count is the same on every device
     if (n_cu == 0) {
         int dev = 0;
@@ -482,9 +490,9 @@ int launch_tile_t(const TileArgs& a, hipStream_t s)
         RECO_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
         if (n_cu <= 0) n_cu = 256;
     }
-    const int64_t tiles = ceil_div64(a.N, TI) * ceil_div64(a.U, TUB);
-    const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);   // one resident 8-wave workgroup per CU
-    hipLaunchKernelGGL((tower_tile_kernel<G, L3>), dim3(grid), dim3(TILE_THREADS), lds, s, a);
+    const int64_t tiles = ceil_div64(a.N, TI) * ceil_div64(a.U, TUBX);
+    const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);   // one resident workgroup per CU
+    hipLaunchKernelGGL((tower_tile_kernel<G, L3, THREADS, TUBX>), dim3(grid), dim3(THREADS), lds, s, a);
     RECO_CHECK_LAUNCH();
     return RECO_OK;
 }

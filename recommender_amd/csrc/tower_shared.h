@@ -107,28 +107,28 @@ __device__ __forceinline__ void tile_queue_fetch(const TileArgs& a, int tid, int
     if (tid == 0) *slot = a.next_tile ? (long long)gridDim.x + (long long)atomicAdd(a.next_tile, 1u) : (long long)fallback;
 }
 
-template <int G>
+template <int G, int THREADS = TILE_THREADS>
 struct TileStage {
-    static constexpr int NQ = TI * (H1 / 4) / TILE_THREADS;                 // float4 of Q per thread (4)
-    static constexpr int NG = G > 0 ? (TI * (G / 4) + TILE_THREADS - 1) / TILE_THREADS : 0;
+    static constexpr int NQ = (TI * (H1 / 4) + THREADS - 1) / THREADS;      // float4 of Q per thread (4; 3 at 768 threads)
+    static constexpr int NG = G > 0 ? (TI * (G / 4) + THREADS - 1) / THREADS : 0;
     f32x4 q[NQ];
     f32x4 g[NG > 0 ? NG : 1];
 };
 
-template <int G>
-__device__ __forceinline__ void tile_stage_load(const TileArgs& a, int64_t n0, bool count_oob, int tid, TileStage<G>& st)
+template <int G, int THREADS = TILE_THREADS>
+__device__ __forceinline__ void tile_stage_load(const TileArgs& a, int64_t n0, bool count_oob, int tid, TileStage<G, THREADS>& st)
 {
 #pragma unroll
-    for (int s = 0; s < TileStage<G>::NQ; ++s) {
-        const int i = tid + s * TILE_THREADS;
+    for (int s = 0; s < TileStage<G, THREADS>::NQ; ++s) {
+        const int i = tid + s * THREADS;
         const int64_t n = n0 + (i >> 5);
         st.q[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (n < a.N) st.q[s] = reinterpret_cast<const f32x4*>(a.Q + n * H1)[i & 31];
+        if (i < TI * (H1 / 4) && n < a.N) st.q[s] = reinterpret_cast<const f32x4*>(a.Q + n * H1)[i & 31];
     }
     if constexpr (G > 0) {
 #pragma unroll
-        for (int s = 0; s < TileStage<G>::NG; ++s) {
-            const int i = tid + s * TILE_THREADS;
+        for (int s = 0; s < TileStage<G, THREADS>::NG; ++s) {
+            const int i = tid + s * THREADS;
             const int r = i / (G / 4), c = i % (G / 4);
             const int64_t n = n0 + r;
             st.g[s] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -140,18 +140,18 @@ __device__ __forceinline__ void tile_stage_load(const TileArgs& a, int64_t n0, b
     }
 }
 
-template <int G>
-__device__ __forceinline__ void tile_stage_store(float* s_q, float* s_g, int tid, const TileStage<G>& st)
+template <int G, int THREADS = TILE_THREADS>
+__device__ __forceinline__ void tile_stage_store(float* s_q, float* s_g, int tid, const TileStage<G, THREADS>& st)
 {
 #pragma unroll
-    for (int s = 0; s < TileStage<G>::NQ; ++s) {
-        const int i = tid + s * TILE_THREADS;
-        *reinterpret_cast<f32x4*>(s_q + (i >> 5) * QS + (i & 31) * 4) = st.q[s];
+    for (int s = 0; s < TileStage<G, THREADS>::NQ; ++s) {
+        const int i = tid + s * THREADS;
+        if (i < TI * (H1 / 4)) *reinterpret_cast<f32x4*>(s_q + (i >> 5) * QS + (i & 31) * 4) = st.q[s];
     }
     if constexpr (G > 0) {
 #pragma unroll
-        for (int s = 0; s < TileStage<G>::NG; ++s) {
-            const int i = tid + s * TILE_THREADS;
+        for (int s = 0; s < TileStage<G, THREADS>::NG; ++s) {
+            const int i = tid + s * THREADS;
             const int r = i / (G / 4), c = i % (G / 4);
             if (r < TI) *reinterpret_cast<f32x4*>(s_g + r * (G + 4) + c * 4) = st.g[s];
         }
