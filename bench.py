@@ -180,7 +180,7 @@ def main():
                        "parallelism": "user-sharded x%d, replicated tables, RCCL all-gather of top-k" % world},
             "roofline": {"bound": "mfma", "kernel": "tower_tile_kernel<32,true>", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": measured_traffic("tower_tile_kernel<32, true>") if world == 1 else None,
+                         "traffic": measured_traffic("tower_tile_kernel<32, true") if world == 1 else None,
                          "traffic_note": "HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/*_hbm_traffic.json), not live; "
                                          "algorithmic output is 85.3 MB per launch",
                          "kernel_ms": tile_ms, "launches_timed": n_timed, "flop_per_pair_algorithmic": FLOP_PER_PAIR,
