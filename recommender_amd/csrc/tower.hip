@@ -164,7 +164,7 @@ __device__ __forceinline__ float tower_mlp_part(const float* s_img, int lane, X1
     return part;
 }
 
-constexpr bool tile_plds(int g) { return g <= 32; }     // the Hybrid head's 64-wide GMF tile leaves no room for a P tile
+constexpr bool tile_plds(int g) { return g <= 64; }     // P tile in LDS (the Hybrid head's 64-wide GMF tile leaves room for 16 users only)
 
 // THREADS / TUBX: 512 threads x 32 users per tile (2 waves per SIMD), or, once the P rows live in LDS and the kernel needs
 // <= 170 VGPRs, 768 threads x 24 users (3 waves per SIMD).
@@ -477,8 +477,8 @@ template <int G, bool L3>
 int launch_tile_t(const TileArgs& a, hipStream_t s)
 {
     // with the P rows in LDS the kernel needs 143 VGPRs: three waves per SIMD (768 threads, 24 users per tile, LDS 152 KB)
-    // measured 3.35 -> 3.32 ms; the Hybrid head keeps 512 threads x 32 users (P rows in registers)
-    constexpr int THREADS = tile_plds(G) ? 768 : 512, TUBX = tile_plds(G) ? 24 : TUB;
+    // measured 3.35 -> 3.32 ms; the Hybrid head (64-wide GMF tile) has LDS room for 16 users per tile: 512 threads
+    constexpr int THREADS = G <= 32 ? 768 : 512, TUBX = G <= 32 ? 24 : 16;
     constexpr size_t lds = (size_t)(IMG_SIZE + 2 * (TI * QS + (G > 0 ? TI * (G + 4) : 0)) + (tile_plds(G) ? 2 * TUBX * H1 : 0)) * sizeof(float);
     static_assert(lds <= 160 * 1024, "tile kernel LDS budget");
     static bool attr[RECO_MAX_DEVICES] = {};
