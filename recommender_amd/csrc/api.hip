@@ -249,13 +249,15 @@ extern "C" int reco_tower_create(const reco_tower_desc_t* d, void* stream, reco_
     if (tables && d->dm > 0) RECO_REQUIRE(d->user_mlp && d->item_mlp, "tower_create: MLP tables missing");
 
     hipStream_t s = (hipStream_t)stream;
+    int device = -1;
+    RECO_CHECK_HIP(hipGetDevice(&device));
     reco_tower* t = new (std::nothrow) reco_tower();
     if (!t) { reco_set_error("tower_create: out of host memory"); return RECO_ENOMEM; }
     t->d = *d;
     t->mfma = d->dm > 0;
     t->G = d->dg;
     t->has_l3 = d->n_layers == 3;
-    RECO_CHECK_HIP(hipGetDevice(&t->device));
+    t->device = device;
 
     if (t->mfma) {
         const bool neumf = d->n_layers == 3 && d->layer_out[0] == H1 && d->layer_out[1] == H2 && d->layer_out[2] == H3 &&

@@ -180,6 +180,8 @@ def topk_rows(scores, k, exclude=None):
     ld = scores.stride(0) if rows > 1 else N
     if exclude is not None:
         exclude = _mask(exclude, scores)
+        if tuple(exclude.shape) != (rows, N):
+            raise ValueError("exclude mask must have shape (%d, %d), got %s" % (rows, N, tuple(exclude.shape)))
     ids = torch.empty((rows, k), dtype=torch.int32, device=scores.device)
     vals = torch.empty((rows, k), dtype=torch.float32, device=scores.device)
     L = _lib.lib()
@@ -189,6 +191,19 @@ def topk_rows(scores, k, exclude=None):
         check(L.reco_topk_rows(_p(scores), rows, N, ld, k, _p(exclude), N, _p(ids), _p(vals), _p(ws), nbytes,
                                _stream(scores.device)))
     return ids, vals
+
+
+def _check_out(t, shape, dtype, device, name, rows_may_be_strided=False):
+    """A caller-provided output tensor is handed to the kernels as a raw pointer: its extents must be what they assume."""
+    ok = isinstance(t, torch.Tensor) and tuple(t.shape) == tuple(shape) and t.dtype == dtype and t.device == device
+    if ok and t.numel():
+        if rows_may_be_strided:
+            ok = (shape[1] == 1 or t.stride(1) == 1) and (shape[0] == 1 or t.stride(0) >= shape[1])
+        else:
+            ok = t.is_contiguous()
+    if not ok:
+        raise ValueError("%s must be a %s%s tensor of shape %s on %s" % (
+            name, "" if rows_may_be_strided else "contiguous ", str(dtype).replace("torch.", ""), tuple(shape), device))
 
 
 def _mask(m, like):
@@ -264,15 +279,32 @@ class Tower:
         d.dm = int(dm if dm is not None else (user_mlp.shape[1] if user_mlp is not None else 0))
         if len(layers) > 3:
             raise ValueError("reco_hip: at most 3 MLP layers are supported, got %d" % len(layers))
+        # the C side sees raw pointers only: every extent it will assume is checked here
+        for name, t, rows, width in (("user_gmf", user_gmf, d.n_users, d.dg), ("item_gmf", item_gmf, d.n_items, d.dg),
+                                     ("user_mlp", user_mlp, d.n_users, d.dm), ("item_mlp", item_mlp, d.n_items, d.dm)):
+            if t is not None and tuple(t.shape) != (rows, width):
+                raise ValueError("%s has shape %s, expected (%d, %d)" % (name, tuple(t.shape), rows, width))
+        for t in keep:
+            if t.device != dev:
+                raise ValueError("all tower tensors must live on %s, got one on %s" % (dev, t.device))
         d.n_layers = len(layers)
+        fan_in = 2 * d.dm
         for i, (w, b) in enumerate(layers):
             w = f(w, "W[%d]" % i, 2); b = f(b, "b[%d]" % i, 1)
+            if w.shape[1] != fan_in or b.numel() != w.shape[0] or w.device != dev or b.device != dev:
+                raise ValueError("MLP layer %d: weight %s / bias %s do not fit an input of width %d on %s"
+                                 % (i, tuple(w.shape), tuple(b.shape), fan_in, dev))
             d.W[i] = w.data_ptr(); d.b[i] = b.data_ptr(); d.layer_out[i] = w.shape[0]
+            fan_in = w.shape[0]
+        if w_predict.numel() != d.dg + (fan_in if layers else 0) or b_predict.numel() != 1:
+            raise ValueError("predict layer has %d weights / %d biases, expected %d / 1 (gmf %d + mlp %d)"
+                             % (w_predict.numel(), b_predict.numel(), d.dg + (fan_in if layers else 0), d.dg, fan_in if layers else 0))
         wp = f(w_predict.reshape(-1), "w_predict", 1); bp = f(b_predict.reshape(-1), "b_predict", 1)
         d.w_predict = wp.data_ptr(); d.b_predict = bp.data_ptr()
         d.act = ACTS[act]; d.lo = lo; d.hi = hi
         d.precision = PRECISIONS[self.precision]
         self.n_users, self.n_items = int(d.n_users), int(d.n_items)
+        self.dg, self.dm = int(d.dg), int(d.dm)
         self._keep = keep
         self._h = ctypes.c_void_p()
         self._L = _lib.lib()
@@ -307,6 +339,10 @@ class Tower:
         ref = u_mlp if u_mlp is not None else u_gmf
         B = ref.shape[0]
         tens = [None if t is None else _f32(t, "rows", 2) for t in (u_gmf, i_gmf, u_mlp, i_mlp)]
+        for name, t, width in (("u_gmf", tens[0], self.dg), ("i_gmf", tens[1], self.dg), ("u_mlp", tens[2], self.dm), ("i_mlp", tens[3], self.dm)):
+            if width and (t is None or tuple(t.shape) != (B, width) or t.device != self.device):
+                raise ValueError("%s must be a [%d, %d] float32 tensor on %s, got %s"
+                                 % (name, B, width, self.device, None if t is None else tuple(t.shape)))
         out = torch.empty(B, dtype=torch.float32, device=self.device)
         nbytes = self._L.reco_tower_rows_workspace_bytes(B)
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.device)
@@ -331,6 +367,8 @@ class Tower:
         N = cands.numel() if cands is not None else self.n_items
         if out is None:
             out = torch.empty((U, N), dtype=torch.float32, device=self.device)
+        else:
+            _check_out(out, (U, N), torch.float32, self.device, "out", rows_may_be_strided=True)
         nbytes = self._L.reco_tower_matrix_workspace_bytes(U, N)
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
@@ -359,8 +397,12 @@ class Tower:
             vals = torch.empty((U, k), dtype=torch.float32, device=self.device)
         else:
             ids, vals = out
+            _check_out(ids, (U, k), torch.int32, self.device, "out[0] (ids)")
+            _check_out(vals, (U, k), torch.float32, self.device, "out[1] (scores)")
         if ws is None:
             ws = self.topk_workspace(U, N, k)
+        elif not (isinstance(ws, torch.Tensor) and ws.dtype == torch.uint8 and ws.device == self.device and ws.is_contiguous()):
+            raise ValueError("ws must be the uint8 tensor topk_workspace() returned, on %s" % self.device)
         with torch.cuda.device(self.device):
             check(self._L.reco_tower_score_topk(self._h, _p(uptr), base, U, _p(cands), N, k, _p(exclude), N, _p(ids),
                                                 _p(vals), _p(ws), ws.numel(), _stream(self.device)))

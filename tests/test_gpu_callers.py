@@ -155,3 +155,46 @@ def test_c_abi_rejects_bad_arguments_with_error_codes_not_faults():
     with pytest.raises(ValueError):
         ops.Tower(w_predict=torch.zeros(64, device=dev), b_predict=torch.zeros(1, device=dev), precision="fp8")
     torch.cuda.synchronize()
+
+
+def test_host_wrappers_refuse_tensors_whose_extents_the_kernels_would_overrun():
+    """Caller-provided outputs / rows / weights go to the kernels as raw pointers: wrong extents raise before any launch."""
+    from recommender_amd import ops
+    from recommender_amd.helpers import NCF
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    m = NCF(40, 30, 32, 3, 0.0, "NeuMF-end").eval().cuda()
+    t = m._tower(dev)
+    ids = torch.empty(40, 5, dtype=torch.int32, device=dev); vals = torch.empty(40, 5, device=dev)
+    got = t.score_topk(None, 5, out=(ids, vals))
+    assert got[0] is ids and got[1] is vals
+    for bad in ((ids[:39], vals), (ids, vals[:, :4]), (ids.long(), vals), (ids.cpu(), vals), (ids.t().contiguous().t(), vals)):
+        with pytest.raises(ValueError):
+            t.score_topk(None, 5, out=bad)
+    with pytest.raises(ValueError):
+        t.score_topk(None, 5, ws=torch.empty(1 << 20, dtype=torch.float32, device=dev))
+    wide = torch.empty(40, 64, device=dev)
+    assert t.score_matrix(out=wide[:, :30]).data_ptr() == wide.data_ptr()              # a column block is written in place
+    for bad in (torch.empty(40, 29, device=dev), torch.empty(30, 40, device=dev).t(), torch.empty(40, 30, dtype=torch.float64, device=dev)):
+        with pytest.raises(ValueError):
+            t.score_matrix(out=bad)
+    ug, ig = torch.randn(7, 32, device=dev), torch.randn(7, 32, device=dev)
+    um, im = torch.randn(7, 128, device=dev), torch.randn(7, 128, device=dev)
+    assert t.score_rows(ug, ig, um, im).shape == (7,)
+    for bad in ((ug[:6], ig, um, im), (ug, ig, um[:, :64], im), (ug, ig, um, None)):
+        with pytest.raises(ValueError):
+            t.score_rows(*bad)
+    sd = m.state_dict()
+    layers = [(sd["MLP_layers.%d.weight" % i], sd["MLP_layers.%d.bias" % i]) for i in (1, 4, 7)]
+    kw = dict(user_gmf=sd["embed_user_GMF.weight"], item_gmf=sd["embed_item_GMF.weight"], user_mlp=sd["embed_user_MLP.weight"],
+              item_mlp=sd["embed_item_MLP.weight"], layers=layers, w_predict=sd["predict_layer.weight"], b_predict=sd["predict_layer.bias"])
+    ops.Tower(**kw)
+    for change in (dict(item_mlp=sd["embed_item_MLP.weight"][:29]), dict(user_gmf=sd["embed_user_GMF.weight"][:, :16]),
+                   dict(layers=[layers[0], layers[2], layers[1]]), dict(w_predict=sd["predict_layer.weight"][:, :32]),
+                   dict(b_predict=torch.zeros(2, device=dev))):
+        with pytest.raises(ValueError):
+            ops.Tower(**{**kw, **change})
+    sc = torch.randn(6, 50, device=dev)
+    with pytest.raises(ValueError):
+        ops.topk_rows(sc, 3, exclude=torch.zeros(6, 49, dtype=torch.bool, device=dev))
+    torch.cuda.synchronize()
