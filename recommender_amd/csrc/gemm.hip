@@ -281,7 +281,11 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
     __syncthreads();
 
     for (int64_t t = 0; t < nt; ++t) {
+#ifdef RECO_ABL_GEMM_NO_LOAD       // timing-only ablation: every K tile re-stages the first one's registers
+        if (t + 1 < nt && a.K < 0) load_tile(t + 1);
+#else
         if (t + 1 < nt) load_tile(t + 1);
+#endif
         if constexpr (SPLIT) {
             const unsigned short* pa = reinterpret_cast<const unsigned short*>(smem + (t & (NBUF - 1)) * BUF) + (wm * (BM / 2) + i) * LSB + 8 * h;
             const unsigned short* pb = reinterpret_cast<const unsigned short*>(smem + (t & (NBUF - 1)) * BUF) + BM * LSB + (wn * (BN / 2) + i) * LSB + 8 * h;
@@ -345,6 +349,9 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
             for (int r = 0; r < 16; ++r) {
                 const int64_t m = m0 + wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (m >= a.M) continue;
+#ifdef RECO_ABL_GEMM_NO_STORE      // timing-only ablation: the stores stay in the code but never execute
+                if (acc[tm][tn][r] != 12345.678f) continue;
+#endif
                 if (a.splits > 1) a.partial[((int64_t)split * a.M + m) * a.N + n] = acc[tm][tn][r];
                 else a.C[m * a.ldc + n] = apply_act(acc[tm][tn][r] + ((a.bias && a.bias_rows) ? a.bias[m] : bv), a.act, a.lo, a.hi);
             }

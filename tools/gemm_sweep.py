@@ -18,7 +18,11 @@ def t_ms(fn, reps=20, warm=3):
     return sorted(a.elapsed_time(b) for a, b in zip(e0, e1))[reps // 2]
 
 
-shapes = [(3706, 6040, 500), (3712, 6144, 512), (3712, 6144, 1024), (3712, 6144, 2048), (3712, 6144, 4096),
+if len(sys.argv) > 1 and sys.argv[1] == "--short":
+    SHORT = [(3706, 6040, 500), (4096, 4096, 32), (4096, 4096, 128), (4096, 4096, 512), (4096, 4096, 2048), (3706, 500, 6040)]
+else:
+    SHORT = None
+shapes = SHORT or [(3706, 6040, 500), (3712, 6144, 512), (3712, 6144, 1024), (3712, 6144, 2048), (3712, 6144, 4096),
           (4096, 4096, 512), (4096, 4096, 4096), (8192, 8192, 512), (2048, 4096, 512), (4096, 8192, 512),
           (3706, 500, 6040), (3712, 512, 6144), (3712, 512, 4096), (4096, 512, 8192)]
 for (M, N, K) in shapes:
