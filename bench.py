@@ -43,7 +43,7 @@ def build_model(n_users, device):
     return m.to(device)
 
 
-def cpu_baseline(model, check_ids, check_vals, budget_s=12.0):
+def cpu_baseline(model, check_ids, check_vals, budget_s=12.0, budget_1t_s=5.0):
     """Reference PyTorch CPU forward (oracle/torch_ref.py: the same ATen ops) on a bounded user sample."""
     from oracle import torch_ref as T
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
@@ -62,7 +62,19 @@ def cpu_baseline(model, check_ids, check_vals, budget_s=12.0):
         el = time.perf_counter() - t0
         if el >= budget_s:
             break
+    # the same loop on one thread (SURVEY 8d asks for both)
+    torch.set_num_threads(1)
+    done1, t1 = 0, time.perf_counter()
+    while True:
+        s = done1 % (N_USERS - chunk)
+        T.ncf_score_topk(sd, torch.arange(s, s + chunk), K, chunk)
+        done1 += chunk
+        el1 = time.perf_counter() - t1
+        if el1 >= budget_1t_s:
+            break
+    torch.set_num_threads(threads)
     return {"value": done * N_ITEMS / el, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "value_1_thread": done1 * N_ITEMS / el1,
             "sample": "%d users x %d items (chunks of %d users x catalog, score + top-%d) in %.1f s; torch %s CPU, "
                       "%d intra-op threads; matches GPU top-%d scores: %s, ids equal %.4f" % (
                           done, N_ITEMS, chunk, K, el, torch.__version__, threads, K, ok, same_ids)}
