@@ -431,6 +431,7 @@ static const int64_t kTopkExtraRows = 8192;               // bound of rows*split
 
 static int64_t default_chunk(int64_t U, int64_t N)
 {
+    if (N <= 0) return U;
     int64_t c = (int64_t)(kScoreChunkBytes / ((size_t)N * sizeof(float)));
     if (c < 32) c = 32;
     return c < U ? c : U;

@@ -299,6 +299,7 @@ int choose_splits(int64_t rows, int64_t N, int k)
 
 size_t topk_workspace_bytes(int64_t rows, int64_t N, int k)
 {
+    if (rows <= 0 || N <= 0 || k <= 0) return 0;
     const int splits = choose_splits(rows, N, k);
     return splits > 1 ? align_up((size_t)rows * splits * k * sizeof(u64), 256) : 0;
 }

@@ -316,3 +316,47 @@ def test_topk_random_sweep():
         oid, oval = O.topk_rows(O.mask_seen(sc, ex) if case % 2 else sc, k)
         assert np.array_equal(ids.cpu().numpy(), oid), (case, rows, N, k, ld)
         assert np.array_equal(vals.cpu().numpy(), oval), (case, rows, N, k, ld)
+
+
+@pytest.mark.parametrize("tag", ["end", "gmf"])
+def test_empty_and_ragged_batches(g2, g3, tag, tower_precision):
+    """Empty inputs return empty outputs (what the reference's ATen ops do); every batch length around the kernels' 32 / 64 /
+    tile boundaries gives the same scores as the full matrix; k == N returns the whole row sorted."""
+    from recommender_amd import ops
+    m = _ncf_from_sd(golden_sd(g2, tag))
+    ref = g2[tag + "__scores"]
+    U, I = ref.shape
+    e = torch.empty(0, dtype=torch.long).cuda()
+    assert tuple(m(e, e).shape) == (0,)
+    assert tuple(m.score_matrix(users=e).shape) == (0, I)
+    ids, vals = m.score_topk(e, 5)
+    assert tuple(ids.shape) == (0, 5) and tuple(vals.shape) == (0, 5)
+    rng = np.random.default_rng(7)
+    for B in (1, 2, 31, 32, 33, 63, 64, 65, 95, 127, 129, 255, 257, 1000):
+        u = rng.integers(0, U, B); i = rng.integers(0, I, B)
+        s = m(torch.from_numpy(u).cuda(), torch.from_numpy(i).cuda()).cpu().numpy()
+        assert_close(s, ref[u, i], what="%s ragged batch B=%d" % (tag, B))
+    for nu, ni in ((1, 1), (1, I), (U, 1), (23, 63), (25, 65), (24, 64), (49, 129)):
+        nu, ni = min(nu, U), min(ni, I)
+        uu = rng.choice(U, nu, replace=False); cc = rng.choice(I, ni, replace=False)
+        sm = m.score_matrix(users=torch.from_numpy(uu).cuda(), candidates=torch.from_numpy(cc).cuda()).cpu().numpy()
+        assert_close(sm, ref[np.ix_(uu, cc)], what="%s ragged tile %dx%d" % (tag, nu, ni))
+    # k == N: the whole candidate list, sorted by descending score with the lower position first among equals
+    cc = rng.choice(I, 17, replace=False)
+    ids, vals = m.score_topk(torch.arange(9).cuda(), 17, candidates=torch.from_numpy(cc).cuda())
+    oid, oval = O.topk_rows(ref[np.ix_(np.arange(9), cc)], 17)
+    assert_close(vals.cpu().numpy(), oval, what="k == N scores")
+    assert (np.sort(ids.cpu().numpy(), axis=1) == np.arange(17)).all()
+    # the stand-alone ops
+    assert tuple(ops.gather_rows(torch.randn(5, 8).cuda(), e).shape) == (0, 8)
+    assert tuple(ops.linear(torch.empty(0, 12).cuda(), torch.randn(7, 12).cuda(), torch.randn(7).cuda(), "relu").shape) == (0, 7)
+    i0, v0 = ops.topk_rows(torch.empty(0, 40).cuda(), 3)
+    assert tuple(i0.shape) == (0, 3) and tuple(v0.shape) == (0, 3)
+    from recommender_amd.autorec.utils.model import AutoRec
+    a = AutoRec(193, 89, 64, True)
+    a.load_state_dict({k: torch.from_numpy(v) for k, v in golden_sd(g3, "a").items()})
+    a = a.eval().cuda()
+    assert tuple(a(torch.empty(0, 193).cuda()).shape) == (0, 193)
+    x1 = torch.from_numpy(g3["a__train"].astype(np.float32).T[:1].copy()).cuda()      # one item vector, as the engine sends it
+    assert_close(a(x1).cpu().numpy(), g3["a__raw"][:1], atol=2.0 * float(np.abs(g3["a__raw"] - g3["a__raw64"]).max()), what="B = 1 AutoRec")
+    torch.cuda.synchronize()
