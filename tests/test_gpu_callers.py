@@ -198,3 +198,34 @@ def test_host_wrappers_refuse_tensors_whose_extents_the_kernels_would_overrun():
     with pytest.raises(ValueError):
         ops.topk_rows(sc, 3, exclude=torch.zeros(6, 49, dtype=torch.bool, device=dev))
     torch.cuda.synchronize()
+
+
+def test_concurrent_callers_on_their_own_streams_share_one_model(g2):
+    """SURVEY 8b threading: the library holds no per-call global state, so threads on separate streams may score through the
+    same handle at once (every call carves its own workspace; the handle is read-only after creation)."""
+    import threading
+    m = _ncf(g2)
+    ref_ids, ref_vals = m.score_topk(None, 10)
+    ref_pairs = m(torch.arange(257).cuda() % 257, torch.arange(257).cuda() % 131)
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(seed):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(20):
+                    ids, vals = m.score_topk(None, 10)
+                    pairs = m(torch.arange(257).cuda() % 257, torch.arange(257).cuda() % 131)
+                st.synchronize()
+                if not (torch.equal(ids, ref_ids) and torch.equal(vals, ref_vals) and torch.equal(pairs, ref_pairs)):
+                    errors.append("thread %d: results differ from the serial call" % seed)
+        except Exception as exc:  # noqa: BLE001
+            errors.append("thread %d: %r" % (seed, exc))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
