@@ -10,6 +10,8 @@
  * Conventions
  *   - every pointer is a DEVICE pointer unless the comment says "host";
  *   - floats are fp32, contiguous, row-major; Linear weights are [out, in] as nn.Linear stores them;
+ *   - embedding tables, row blocks and gather outputs are 16-byte aligned and their widths multiples of 4 (rows move as
+ *     float4; anything torch allocates qualifies); a violation is RECO_EINVAL, never a misaligned access;
  *   - ids (users, items, candidate lists) are int64 as the reference's torch LongTensors; returned
  *     top-k positions are int32;
  *   - `stream` is a hipStream_t passed as void*; work is only enqueued, never synchronised,

@@ -247,6 +247,8 @@ extern "C" int reco_tower_create(const reco_tower_desc_t* d, void* stream, reco_
     const bool tables = d->n_users > 0 && d->n_items > 0;
     if (tables && d->dg > 0) RECO_REQUIRE(d->user_gmf && d->item_gmf, "tower_create: GMF tables missing");
     if (tables && d->dm > 0) RECO_REQUIRE(d->user_mlp && d->item_mlp, "tower_create: MLP tables missing");
+    RECO_REQUIRE((uintptr_t)d->user_gmf % 16 == 0 && (uintptr_t)d->item_gmf % 16 == 0 && (uintptr_t)d->user_mlp % 16 == 0 &&
+                 (uintptr_t)d->item_mlp % 16 == 0, "tower_create: embedding tables must be 16-byte aligned (rows are read as float4)");
 
     hipStream_t s = (hipStream_t)stream;
     int device = -1;
@@ -349,6 +351,8 @@ extern "C" int reco_tower_score_rows(reco_tower_t* t, const float* u_gmf, const 
     hipStream_t s = (hipStream_t)stream;
     const reco_tower_desc_t& d = t->d;
     if (d.dg > 0) RECO_REQUIRE(u_gmf && i_gmf, "score_rows: GMF rows missing");
+    RECO_REQUIRE((uintptr_t)u_gmf % 16 == 0 && (uintptr_t)i_gmf % 16 == 0 && (uintptr_t)u_mlp % 16 == 0 && (uintptr_t)i_mlp % 16 == 0,
+                 "score_rows: row blocks must be 16-byte aligned (rows are read as float4)");
     if (!t->mfma)
         return gmf_launch_pairs(u_gmf, i_gmf, d.w_predict, nullptr, nullptr, B, B, B, d.dg, out, t->bp, d.act, d.lo,
                                 d.hi, nullptr, s);

@@ -143,6 +143,7 @@ extern "C" int reco_gather_rows(const float* table, int64_t rows, int dim, const
     RECO_REQUIRE(table && idx && out, "gather_rows: null pointer");
     RECO_REQUIRE(dim > 0 && dim % 4 == 0, "gather_rows: dim must be a positive multiple of 4, got %d", dim);
     RECO_REQUIRE(rows > 0, "gather_rows: empty table");
+    RECO_REQUIRE((uintptr_t)table % 16 == 0 && (uintptr_t)out % 16 == 0, "gather_rows: table and out must be 16-byte aligned");
     const int sh = log2_exact(dim / 4);
     if (sh >= 0)
         hipLaunchKernelGGL(gather_rows_kernel<true>, dim3(stream_grid(B * (dim / 4))), dim3(256), 0, (hipStream_t)stream,
@@ -170,6 +171,8 @@ extern "C" int reco_neumf_gather(const float* Eu_g, const float* Ei_g, const flo
     RECO_REQUIRE(ld_gmf % 4 == 0 && ld_mlp % 4 == 0 && (!gmf_prod || ld_gmf >= dg) && (!mlp_in || ld_mlp >= 2 * dm),
                  "neumf_gather: bad output strides %lld / %lld", (long long)ld_gmf, (long long)ld_mlp);
     RECO_REQUIRE((uintptr_t)gmf_prod % 16 == 0 && (uintptr_t)mlp_in % 16 == 0, "neumf_gather: outputs must be 16-byte aligned");
+    RECO_REQUIRE((uintptr_t)Eu_g % 16 == 0 && (uintptr_t)Ei_g % 16 == 0 && (uintptr_t)Eu_m % 16 == 0 && (uintptr_t)Ei_m % 16 == 0,
+                 "neumf_gather: tables must be 16-byte aligned");
     FusedArgs a{Eu_g, Ei_g, Eu_m, Ei_m, n_users, n_items, dg / 4, dm / 4, user, item, B, gmf_prod, mlp_in, ld_gmf / 4, ld_mlp / 4, oob};
     const int64_t work = B * (mlp_in ? 2 * (dm / 4) : dg / 4);
     const int sh_m = mlp_in ? log2_exact(2 * (dm / 4)) : 0, sh_g = gmf_prod ? log2_exact(dg / 4) : 0;
