@@ -112,8 +112,10 @@ class AutoRec(nn.Module):
         Same numbers as inference_engine.py:266-272 (one full forward per item, keep column user_id).
         """
         hit = _dev_cache.get(self)
+        if hit is not None:
+            hit = self._weights(hit[1][0].device)           # a weight update since cache_hidden drops the cached H with the old copy
         if hit is None or "H" not in hit[2]:
-            raise RuntimeError("call cache_hidden(train_matrix) first")
+            raise RuntimeError("call cache_hidden(train_matrix) first (and again after the weights change)")
         _, (we, be, wd, bd), extra = hit
         if not 0 <= int(user_id) < wd.shape[0]:
             raise IndexError("user id %d out of range [0, %d)" % (int(user_id), wd.shape[0]))
