@@ -92,6 +92,13 @@ class NCFInferenceEngine:
             cands = torch.as_tensor(uniq, dtype=torch.int64)
             n = len(uniq)
         k = min(k, n)
+        if k <= 0:
+            return []                                                          # scores[...][:0]
+        if k > 128:                        # beyond the schema's k <= 100 (schemas.py:61) and the wavefront select: host sort
+            sc = self.model.score_matrix(torch.tensor([user_id]), cands)[0].cpu().numpy()
+            order = np.argsort(-sc, kind="stable")[:k]
+            ids = order if cands is None else cands.numpy()[order]
+            return [(int(i), float(v)) for i, v in zip(ids, sc[order])]
         # ids were validated above, so the kernel-side range report (a sync) is skipped; ids and scores come back in ONE copy
         device = self.model._compute_device()
         buf, ids, vals = packed_topk_buffers(1, k, device)
@@ -156,6 +163,8 @@ class AutoRecInferenceEngine:
                 raise RequestError(status_code=400, detail="No valid candidate items")
             n = len(cand)
         k = min(k, n)
+        if k <= 0:
+            return []
         sc = self._user_scores(user_id, cand)
         if k <= 128:
             ids, vals = ops.topk_rows(sc.view(1, -1), k)                        # ties: lowest candidate position first, as the stable sort

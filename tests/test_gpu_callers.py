@@ -34,6 +34,9 @@ def test_ncf_engine_matches_reference_engine_semantics(g2):
     uniq = list(set(cand))
     want = [uniq[j] for j in np.argsort(ref[42, uniq])[::-1]]
     assert [r[0] for r in rec] == want
+    assert eng.recommend(42, k=0) == []
+    rec = eng.recommend(42, k=131)                                                          # past the wavefront select's k <= 128
+    assert [r[0] for r in rec] == np.argsort(-ref[42], kind="stable").tolist()
     for bad in (lambda: eng.predict(257, 0), lambda: eng.predict(0, -1), lambda: eng.recommend(0, 5, [131]), lambda: eng.recommend(0, 5, [])):
         with pytest.raises(RequestError) as e:
             bad()
