@@ -360,3 +360,26 @@ def test_empty_and_ragged_batches(g2, g3, tag, tower_precision):
     x1 = torch.from_numpy(g3["a__train"].astype(np.float32).T[:1].copy()).cuda()      # one item vector, as the engine sends it
     assert_close(a(x1).cpu().numpy(), g3["a__raw"][:1], atol=2.0 * float(np.abs(g3["a__raw"] - g3["a__raw64"]).max()), what="B = 1 AutoRec")
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("tag", ["end", "mlp", "gmf"])
+def test_tower_random_request_sweep(g2, tag, tower_precision):
+    """Random requests against the reference's all-pairs matrix: user lists and candidate lists with repeats, every k up to the
+    list length, exclusion masks; the select is checked against the oracle's rule on the kernel's own scores (bit-exact)."""
+    m = _ncf_from_sd(golden_sd(g2, tag))
+    ref = g2[tag + "__scores"]
+    U, I = ref.shape
+    rng = np.random.default_rng(11)
+    for trial in range(24):
+        nu = int(rng.integers(1, 70)); nc = int(rng.integers(1, 140))
+        users = rng.integers(0, U, nu); cands = rng.integers(0, I, nc)            # repeats allowed on both sides
+        ut = torch.from_numpy(users).cuda(); ct = torch.from_numpy(cands).cuda()
+        sm = m.score_matrix(ut, ct).cpu().numpy()
+        assert_close(sm, ref[np.ix_(users, cands)], what="%s trial %d matrix %dx%d" % (tag, trial, nu, nc))
+        k = int(rng.integers(1, min(nc, 128) + 1))
+        mask = rng.random((nu, nc)) < 0.3 if trial % 2 else None
+        ids, vals = m.score_topk(ut, k, ct, exclude=None if mask is None else torch.from_numpy(mask).cuda())
+        want = sm if mask is None else O.mask_seen(sm.copy(), mask)
+        oid, oval = O.topk_rows(want, k)
+        assert np.array_equal(ids.cpu().numpy(), oid), "%s trial %d ids (k=%d)" % (tag, trial, k)
+        assert np.array_equal(vals.cpu().numpy(), oval), "%s trial %d scores" % (tag, trial)
