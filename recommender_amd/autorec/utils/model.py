@@ -78,7 +78,11 @@ class AutoRec(nn.Module):
         we, be, wd, bd = self._weights(device)[1]
         h = ops.linear(m, we, be, act="sigmoid", x_transposed=True)
         act = (None, 0.0, 0.0) if clamp is None else ("clamp", float(clamp[0]), float(clamp[1]))
-        return ops.linear(wd, h, bd, act=act[0], lo=act[1], hi=act[2], bias_per_row=True)
+        # rows padded to whole 128-byte lines (3706 -> 3712 floats): aligned stores in the GEMM epilogue, float4 reads in the
+        # top-k scan; the result is the [users, items] view of that buffer
+        n_users, n_items = wd.shape[0], h.shape[0]
+        buf = torch.empty((n_users, (n_items + 31) // 32 * 32), dtype=torch.float32, device=device)
+        return ops.linear(wd, h, bd, act=act[0], lo=act[1], hi=act[2], bias_per_row=True, out=buf[:, :n_items])
 
     def recommend_topk(self, train_matrix, k=10, users=None, mask_seen=True, clamp=(1.0, 5.0)):
         """Per-user top-k of the reconstruction, seen items pushed to -1e10 as helper.py:313.

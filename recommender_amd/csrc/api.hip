@@ -433,17 +433,21 @@ static const size_t kScoreChunkBytes = (size_t)1 << 30;   // ~1 GiB of score row
 static const int64_t kServingUsers = 16;                  // at most this many users: a request, not a batch job
 static const int64_t kTopkExtraRows = 8192;               // bound of rows*splits - rows in topk.hip choose_splits
 
+// leading dimension of the internal score rows: whole 128-byte lines, so that a wave's 32-score store is one line and the
+// select reads rows as float4 (N = 3533 rows would otherwise start at odd 4-byte offsets)
+static int64_t score_ld(int64_t N) { return (N + 31) / 32 * 32; }
+
 static int64_t default_chunk(int64_t U, int64_t N)
 {
     if (N <= 0) return U;
-    int64_t c = (int64_t)(kScoreChunkBytes / ((size_t)N * sizeof(float)));
+    int64_t c = (int64_t)(kScoreChunkBytes / ((size_t)score_ld(N) * sizeof(float)));
     if (c < 32) c = 32;
     return c < U ? c : U;
 }
 
 static size_t topk_chunk_bytes(int64_t Uc, int64_t N, int k)
 {
-    return kQueueBytes + proj_bytes(N) + proj_bytes(Uc) + align_up((size_t)Uc * N * sizeof(float), 256) +
+    return kQueueBytes + proj_bytes(N) + proj_bytes(Uc) + align_up((size_t)Uc * score_ld(N) * sizeof(float), 256) +
            align_up((size_t)(Uc + kTopkExtraRows) * k * sizeof(uint64_t), 256);
 }
 
@@ -481,7 +485,8 @@ extern "C" int reco_tower_score_topk(reco_tower_t* t, const int64_t* users, int6
     unsigned int* queue = t->mfma ? reinterpret_cast<unsigned int*>(w) : nullptr; w += kQueueBytes;
     float* Q = reinterpret_cast<float*>(w); w += proj_bytes(N);
     float* P = reinterpret_cast<float*>(w); w += proj_bytes(Uc);
-    float* scores = reinterpret_cast<float*>(w); w += align_up((size_t)Uc * N * sizeof(float), 256);
+    const int64_t ldN = score_ld(N);
+    float* scores = reinterpret_cast<float*>(w); w += align_up((size_t)Uc * ldN * sizeof(float), 256);
     void* tws = w;
     const size_t tws_bytes = align_up((size_t)(Uc + kTopkExtraRows) * k * sizeof(uint64_t), 256);
 
@@ -496,9 +501,9 @@ extern "C" int reco_tower_score_topk(reco_tower_t* t, const int64_t* users, int6
     }
     for (int64_t c0 = 0; c0 < U; c0 += Uc) {
         const int64_t n = U - c0 < Uc ? U - c0 : Uc;
-        rc = score_matrix_impl(t, users ? users + c0 : nullptr, user_base + c0, n, cands, N, Q, scores, N, P, Q, queue, s);
+        rc = score_matrix_impl(t, users ? users + c0 : nullptr, user_base + c0, n, cands, N, Q, scores, ldN, P, Q, queue, s);
         if (rc) return rc;
-        rc = launch_topk_rows(scores, n, N, N, k, exclude ? exclude + c0 * ld_ex : nullptr, ld_ex, out_ids + c0 * k,
+        rc = launch_topk_rows(scores, n, N, ldN, k, exclude ? exclude + c0 * ld_ex : nullptr, ld_ex, out_ids + c0 * k,
                               out_scores + c0 * k, tws, tws_bytes, s);
         if (rc) return rc;
     }

@@ -209,14 +209,14 @@ def _check_out(t, shape, dtype, device, name, rows_may_be_strided=False):
 def _mask(m, like):
     if not isinstance(m, torch.Tensor):
         m = torch.as_tensor(m)
-    if m.dtype == torch.bool:
-        m = m.to(torch.uint8)
-    if m.dtype != torch.uint8:
+    if m.dtype not in (torch.bool, torch.uint8):
         raise TypeError("exclude mask must be bool or uint8")
     m = m.to(like.device)
     if m.dim() != 2:
         raise ValueError("exclude mask must be 2-D")
-    return m if m.is_contiguous() else m.contiguous()
+    if not m.is_contiguous():
+        m = m.contiguous()
+    return m.view(torch.uint8) if m.dtype == torch.bool else m       # bool is one byte holding 0 / 1: no conversion pass
 
 
 # ----------------------------------------------------------------------------------------------
