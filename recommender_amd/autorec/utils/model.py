@@ -67,7 +67,8 @@ class AutoRec(nn.Module):
 
         Replaces the 3,706-iteration loop of helper.py:281-292 / inference_engine.py:268-272.
         Item-based: the batch is the transposed matrix (row i = item i's ratings from all users) and the
-        result is transposed back, so R_hat[u, i] = forward(train[:, i])[u].
+        result is transposed back, so R_hat[u, i] = forward(train[:, i])[u].  The returned tensor is a [users, items] view
+        whose row stride is items rounded up to 32 (call .contiguous() if a dense buffer is needed).
         """
         device = self._device_of(train_matrix)
         m = train_matrix.to(device=device, dtype=torch.float32).contiguous()
