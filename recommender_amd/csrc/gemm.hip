@@ -16,6 +16,9 @@
 // fp32.  Loads, tiling, split-K, transposed A and the epilogue are shared with the exact form.
 #include "reco_common.h"
 
+#include <cstdlib>
+#include <cstring>
+
 namespace {
 
 constexpr int BK = 32;
@@ -464,6 +467,9 @@ int launch_linear_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_
     if (s11 >= s12 && s11 >= s21 && s11 >= s22) { bm = 128; bn = 128; }
     else if (s12 >= s21 && s12 >= s22) { bm = 128; bn = 64; }
     else if (s21 >= s22) { bm = 64; bn = 128; }
+#ifdef RECO_DIAG_GEMM_TILE         // diagnostic builds only: force the tile shape
+    if (const char* e = getenv("RECO_GEMM_TILE")) { bm = atoi(e); const char* x = strchr(e, 'x'); bn = x ? atoi(x + 1) : bm; }
+#endif
     if (ws != nullptr) {
         int sp = choose_splits(ceil_div64(M, bm) * ceil_div64(N, bn), K);
         while (sp > 1 && (size_t)sp * M * N * sizeof(float) > ws_bytes) --sp;
