@@ -169,3 +169,47 @@ def test_ranking_metrics(g5):
     mg = [[x for x in row if x >= 0] for row in g5["multi_gt"]]
     assert np.array_equal([hit_multi(g, p) for g, p in zip(mg, g5["preds"])], g5["multi_hr"])
     assert np.allclose([ndcg_multi(g, p) for g, p in zip(mg, g5["preds"])], g5["multi_ndcg"], rtol=0, atol=1e-15)
+
+
+def test_header_is_plain_c_and_a_c_consumer_can_bind_the_library(tmp_path):
+    """The boundary is a C ABI: the header compiles as C99, and a C program (no Python, no torch) binds the library the way a
+    cgo / JNI / N-API stub would: dlopen + the declared prototypes.  No compute call is made (no GPU here)."""
+    import ctypes
+    import shutil
+    from recommender_amd import _lib
+    from recommender_amd._lib import TowerDesc
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    header_dir = os.path.join(ROOT, "include")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
+                    os.path.join(header_dir, "reco_hip.h")], check=True)
+    src = tmp_path / "consumer.c"
+    src.write_text(r'''
+#include <dlfcn.h>
+#include <stdio.h>
+#include "reco_hip.h"
+int main(int argc, char** argv) {
+    void* h = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
+    if (!h) { fprintf(stderr, "%s\n", dlerror()); return 2; }
+    int (*abi)(void) = (int (*)(void))dlsym(h, "reco_abi_version");
+    const char* (*err)(void) = (const char* (*)(void))dlsym(h, "reco_last_error");
+    size_t (*tk)(int64_t, int64_t, int) = (size_t (*)(int64_t, int64_t, int))dlsym(h, "reco_topk_workspace_bytes");
+    size_t (*tw)(int64_t, int64_t, int) = (size_t (*)(int64_t, int64_t, int))dlsym(h, "reco_tower_topk_workspace_bytes");
+    int (*pairs)(reco_tower_t*, const int64_t*, const int64_t*, int64_t, float*, void*) =
+        (int (*)(reco_tower_t*, const int64_t*, const int64_t*, int64_t, float*, void*))dlsym(h, "reco_tower_score_pairs");
+    if (!abi || !err || !tk || !tw || !pairs) return 3;
+    int rc = pairs(NULL, NULL, NULL, 4, NULL, NULL);            /* refused with a code and a message, nothing launched */
+    printf("%d %zu %zu %zu %zu %d %s\n", abi(), sizeof(reco_tower_desc_t), tk(0, 100, 10), tk(0, 0, 0), tw(6038, 3533, 10), rc, err());
+    (void)argc;
+    return 0;
+}
+''')
+    exe = tmp_path / "consumer"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", header_dir, str(src), "-o", str(exe), "-ldl"], check=True)
+    out = subprocess.run([str(exe), _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout.split(None, 6)
+    assert int(out[0]) == _lib.ABI_VERSION
+    assert int(out[1]) == ctypes.sizeof(TowerDesc)
+    assert int(out[2]) == 0 and int(out[3]) == 0                 # zero rows / zero everything: sized, not divided by
+    assert int(out[4]) == _lib.lib().reco_tower_topk_workspace_bytes(6038, 3533, 10)
+    assert int(out[5]) == _lib.EINVAL and "null handle" in out[6]
