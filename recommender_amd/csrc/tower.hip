@@ -164,10 +164,8 @@ __device__ __forceinline__ float tower_mlp_part(const float* s_img, int lane, X1
     return part;
 }
 
-constexpr bool tile_plds(int g) { return g <= 64; }     // P tile in LDS (the Hybrid head's 64-wide GMF tile leaves room for 16 users only)
-
-// THREADS / TUBX: 512 threads x 32 users per tile (2 waves per SIMD), or, once the P rows live in LDS and the kernel needs
-// <= 170 VGPRs, 768 threads x 24 users (3 waves per SIMD).
+// THREADS x TUBX: 768 threads x 24 users per tile (3 waves per SIMD at <= 170 VGPRs) for the NeuMF shapes, 512 x 16 for the
+// Hybrid head, whose 64-wide GMF item tile leaves LDS room for 16 P rows only.
 template <int G, bool L3, int THREADS, int TUBX>
 __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(TileArgs a)
 {
@@ -178,9 +176,8 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_img = smem;
     float* s_buf = smem + IMG_SIZE;
-    // P rows of the tile's users: staged in LDS with the item side when it fits (G <= 32), read per quad by a broadcast
-    // ds_read_b128 instead of living in 64 VGPRs that a global load has to refill at every user switch
-    constexpr bool PLDS = tile_plds(G);
+    // P rows of the tile's users: staged in LDS with the item side and read per quad by a broadcast ds_read_b128 (in 64 VGPRs
+    // they cost a wave per SIMD and a global reload at every user switch)
     constexpr int NP = (TUB * (H1 / 4) + TILE_THREADS - 1) / TILE_THREADS;   // float4 of P per thread (2; 1 at 768 x 24)
     float* s_pbuf = s_buf + 2 * BUF;                            // [2][TUB][H1]
 
@@ -195,26 +192,22 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
     for (int i = tid; i < IMG_SIZE / 4; i += TILE_THREADS)
         reinterpret_cast<f32x4*>(s_img)[i] = reinterpret_cast<const f32x4*>(a.img)[i];
 
-    f32x4 pst[PLDS ? NP : 1];
+    f32x4 pst[NP];
     auto p_stage_load = [&](int64_t t) {
-        if constexpr (PLDS) {
-            const int64_t ub = (t / tiles_n) * TUB;
+        const int64_t ub = (t / tiles_n) * TUB;
 #pragma unroll
-            for (int s = 0; s < NP; ++s) {
-                const int i = tid + s * TILE_THREADS;
-                const int64_t u = ub + (i >> 5);
-                pst[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (i < TUB * (H1 / 4) && u < a.U) pst[s] = reinterpret_cast<const f32x4*>(a.P + u * H1)[i & 31];
-            }
+        for (int s = 0; s < NP; ++s) {
+            const int i = tid + s * TILE_THREADS;
+            const int64_t u = ub + (i >> 5);
+            pst[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < TUB * (H1 / 4) && u < a.U) pst[s] = reinterpret_cast<const f32x4*>(a.P + u * H1)[i & 31];
         }
     };
     auto p_stage_store = [&](int buf) {
-        if constexpr (PLDS) {
 #pragma unroll
-            for (int s = 0; s < NP; ++s)
-                if (tid + s * TILE_THREADS < TUB * (H1 / 4))
-                    reinterpret_cast<f32x4*>(s_pbuf + buf * TUB * H1)[tid + s * TILE_THREADS] = pst[s];
-        }
+        for (int s = 0; s < NP; ++s)
+            if (tid + s * TILE_THREADS < TUB * (H1 / 4))
+                reinterpret_cast<f32x4*>(s_pbuf + buf * TUB * H1)[tid + s * TILE_THREADS] = pst[s];
     };
 
 #ifdef RECO_DIAG_CLOCK
@@ -245,12 +238,6 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
         for (int uu = wave; uu < TUB; uu += TILE_THREADS / 64) {
             const int64_t u = u0 + uu;
             if (u >= a.U) break;
-            f32x4 p[PLDS ? 1 : 16];
-            if constexpr (!PLDS) {
-                const f32x4* prow = reinterpret_cast<const f32x4*>(a.P + u * H1 + 4 * h);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) p[q] = prow[2 * q];
-            }
             f32x4 gu[G > 0 ? G / 8 : 1];
             if constexpr (G > 0) {
                 const int64_t uid = clamp_id(a.users ? a.users[u] : a.user_base + u, a.n_users,
@@ -266,13 +253,6 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
                 // keep the (loop-invariant) weight-image reads inside the loop: hoisted, they would pin ~200 VGPRs
                 asm volatile("" ::: "memory");
                 const float* qrow = s_q + (g * 32 + j) * QS + 4 * h;
-                struct X1Tile {
-                    const float* qrow;
-                    const f32x4* p;
-                    __device__ __forceinline__ f32x4 raw(int q) const { return *reinterpret_cast<const f32x4*>(qrow + 8 * q); }
-                    __device__ __forceinline__ f32x4 finish(int q, f32x4 v) const { return relu4(p[q] + v); }
-                    __device__ __forceinline__ f32x4 passthrough(f32x4 v) const { return v; }
-                };
                 struct PQ { f32x4 q, p; };
                 struct X1TileLds {
                     const float* qrow;
@@ -284,9 +264,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
                     __device__ __forceinline__ f32x4 finish(int, const PQ& v) const { return relu4(v.p + v.q); }
                     __device__ __forceinline__ f32x4 passthrough(const PQ& v) const { return v.q; }
                 };
-                float part;
-                if constexpr (PLDS) part = tower_mlp_part<L3>(s_img, lane, X1TileLds{qrow, s_p + uu * H1 + 4 * h});
-                else part = tower_mlp_part<L3>(s_img, lane, X1Tile{qrow, p});
+                float part = tower_mlp_part<L3>(s_img, lane, X1TileLds{qrow, s_p + uu * H1 + 4 * h});
                 if constexpr (G > 0) {
                     const float* grow = s_g + (g * 32 + j) * GS + h * (G / 2);
 #pragma unroll
@@ -479,7 +457,7 @@ int launch_tile_t(const TileArgs& a, hipStream_t s)
     // with the P rows in LDS the kernel needs 143 VGPRs: three waves per SIMD (768 threads, 24 users per tile, LDS 152 KB)
     // measured 3.35 -> 3.32 ms; the Hybrid head (64-wide GMF tile) has LDS room for 16 users per tile: 512 threads
     constexpr int THREADS = G <= 32 ? 768 : 512, TUBX = G <= 32 ? 24 : 16;
-    constexpr size_t lds = (size_t)(IMG_SIZE + 2 * (TI * QS + (G > 0 ? TI * (G + 4) : 0)) + (tile_plds(G) ? 2 * TUBX * H1 : 0)) * sizeof(float);
+    constexpr size_t lds = (size_t)(IMG_SIZE + 2 * (TI * QS + (G > 0 ? TI * (G + 4) : 0)) + 2 * TUBX * H1) * sizeof(float);
     static_assert(lds <= 160 * 1024, "tile kernel LDS budget");
     static bool attr[RECO_MAX_DEVICES] = {};
     if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&tower_tile_kernel<G, L3, THREADS, TUBX>), lds, attr)) return rc;
