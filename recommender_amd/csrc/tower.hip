@@ -399,7 +399,8 @@ __global__ __launch_bounds__(256) void gmf_pairs_kernel(GmfArgs a)
     if (b < a.B && sub == 0) a.out[b] = epilogue(part + a.bp, a.act, a.lo, a.hi);
 }
 
-// matrix form: one thread per (user, item); user row in registers is re-read through L1.
+// matrix form: a block covers 256 items x 16 users; the 16 user rows are staged in LDS, each thread keeps one item and walks
+// the users (its item row is re-read through L1 per user).
 struct GmfTileArgs {
     const float* EUg;
     const float* EIg;
@@ -418,10 +419,10 @@ struct GmfTileArgs {
 
 __global__ __launch_bounds__(256) void gmf_tile_kernel(GmfTileArgs a)
 {
-    // block = 256 items x 16 users; item rows staged once per block in registers of each thread
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t u0 = (int64_t)blockIdx.y * 16;
-    extern __shared__ __attribute__((aligned(16))) float s_u[];   // [16][G] user rows pre-multiplied? no: raw
+    extern __shared__ __attribute__((aligned(16))) float s_u[];   // [16][G] raw user rows (the product is rounded before the
+                                                                  // predict weight multiplies it, as in the reference)
     for (int i = threadIdx.x; i < 16 * a.G; i += 256) {
         const int64_t u = u0 + i / a.G;
         float v = 0.f;
