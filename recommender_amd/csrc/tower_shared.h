@@ -62,19 +62,21 @@ __device__ __forceinline__ int64_t clamp_id(int64_t id, int64_t n, int32_t* oob)
 }
 
 // ---------------------------------------------------------------------------------------------
-// tile kernel: scores for (user chunk) x (item tile); persistent, one 8-wave workgroup per CU
+// tile kernels: scores for (user chunk) x (item tile); persistent, one workgroup per CU
 // ---------------------------------------------------------------------------------------------
-// Each workgroup loads the weight image once and then walks tiles blockIdx.x, blockIdx.x + grid, ...
+// Each workgroup loads the weight image once and then takes tiles from the work queue below.
 // A tile is TUB users x TI items.  The item side of a tile (Q rows, GMF item rows) lives in one of
-// two LDS buffers: while the 8 waves run the MFMAs of tile i out of buffer i & 1, the global loads of
+// two LDS buffers: while the waves run the MFMAs of tile i out of buffer i & 1, the global loads of
 // tile i + 1 are in flight into registers, are written to the other buffer after the last MFMA and
-// published by the single __syncthreads() per tile.  Wave w owns users w, w + 8, ... of the tile:
-// their P rows (64 VGPRs) stay in registers across the tile's item groups.
+// published by the single __syncthreads() per tile.  Wave w owns users w, w + (waves), ... of the tile.
+// The exact kernel (tower.hip) stages the tile's P rows in LDS the same way and runs 12 or 8 waves with its own
+// THREADS / users-per-tile; the split kernel (tower_split.hip) uses the 512-thread / 32-user defaults below and keeps a
+// user's P row in 64 VGPRs across the tile's item groups (its 62-KB weight image leaves no LDS for a P tile).
 constexpr int TI = 64;         // items per tile (2 MFMA column groups)
 #ifndef RECO_TUB
 #define RECO_TUB 32
 #endif
-constexpr int TUB = RECO_TUB;   // users per tile (4 per wave)
+constexpr int TUB = RECO_TUB;   // users per tile (4 per wave) -- default, see above
 constexpr int QS = H1 + 4;     // padded LDS row stride of the Q tile: conflict-free ds_read_b128 by 16 rows
 constexpr int TILE_THREADS = 512;
 
