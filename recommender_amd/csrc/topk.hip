@@ -283,6 +283,108 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(TopkArgs a)
     }
 }
 
+// Many short rows (the 99-negative protocol: 115,056 rows of 100 scores, ncf.ipynb cell 8): one LANE per row instead of one
+// wave.  A wave-wide sort network costs ~500 instructions for such a row whatever its length; here a lane keeps its row's best K
+// keys sorted in 2 K registers and inserts an element with K compares + 4 K selects, branch-free (~50 instructions per element
+// and 64 rows per instruction).  Rows reach their lanes through an LDS transpose: the block's 256 rows are loaded 32 columns at
+// a time with coalesced 128-byte row segments, stored [row][36] (conflict-free ds_read_b128 by the owning lane).
+// Same order as the wave kernels: descending key, ascending position among equals (a later equal key never displaces).
+template <int K, int VEC>
+__global__ __launch_bounds__(256) void topk_lane_kernel(TopkArgs a)
+{
+    constexpr int SLAB = 32, LSTR = 36;
+    __shared__ __attribute__((aligned(16))) float s_t[256 * LSTR];
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * 256;
+    const int64_t row = r0 + tid;
+    uint32_t lk[K];
+    int32_t li[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { lk[j] = 0u; li[j] = -1; }      // 0 is below every real key (float_key(-inf) = 0x007fffff)
+
+    // slab c0 + 32 is in flight into registers while slab c0 is consumed out of LDS
+    constexpr int NV = VEC == 4 ? 8 : 32;
+    float st[NV * VEC];
+    auto slab_load = [&](int64_t c0) {
+        if constexpr (VEC == 4) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int i = tid + 256 * s;
+                const int64_t rr = r0 + (i >> 3), n = c0 + 4 * (i & 7);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (rr < a.rows) {
+                    const float* src = a.scores + rr * a.ld + n;
+                    if (n + 3 < a.N) v = *reinterpret_cast<const f32x4*>(src);
+                    else {
+                        if (n + 0 < a.N) v.x = src[0];
+                        if (n + 1 < a.N) v.y = src[1];
+                        if (n + 2 < a.N) v.z = src[2];
+                    }
+                }
+                st[4 * s + 0] = v.x; st[4 * s + 1] = v.y; st[4 * s + 2] = v.z; st[4 * s + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                const int i = tid + 256 * s;
+                const int64_t rr = r0 + (i >> 5), n = c0 + (i & 31);
+                st[s] = (rr < a.rows && n < a.N) ? a.scores[rr * a.ld + n] : 0.f;
+            }
+        }
+    };
+    auto slab_store = [&]() {
+        if constexpr (VEC == 4) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int i = tid + 256 * s;
+                *reinterpret_cast<f32x4*>(s_t + (i >> 3) * LSTR + 4 * (i & 7)) = f32x4{st[4 * s], st[4 * s + 1], st[4 * s + 2], st[4 * s + 3]};
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                const int i = tid + 256 * s;
+                s_t[(i >> 5) * LSTR + (i & 31)] = st[s];
+            }
+        }
+    };
+
+    slab_load(0);
+    for (int64_t c0 = 0; c0 < a.N; c0 += SLAB) {
+        slab_store();
+        __syncthreads();
+        if (c0 + SLAB < a.N) slab_load(c0 + SLAB);
+#pragma unroll
+        for (int c4 = 0; c4 < 8; ++c4) {
+            if (c0 + 4 * c4 >= a.N) break;                               // uniform: the row ends inside this slab
+            const f32x4 v = *reinterpret_cast<const f32x4*>(s_t + tid * LSTR + 4 * c4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int64_t n = c0 + 4 * c4 + t;
+                const uint32_t key = n < a.N ? float_key(v[t]) : 0u;     // past the row's end: never enters
+                const int32_t pos = (int32_t)n;
+#pragma unroll
+                for (int j = K - 1; j >= 1; --j) {
+                    const bool here = key > lk[j], above = key > lk[j - 1];
+                    lk[j] = above ? lk[j - 1] : (here ? key : lk[j]);
+                    li[j] = above ? li[j - 1] : (here ? pos : li[j]);
+                }
+                const bool first = key > lk[0];
+                lk[0] = first ? key : lk[0];
+                li[0] = first ? pos : li[0];
+            }
+        }
+        __syncthreads();
+    }
+    if (row < a.rows) {
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (j < a.k) {
+                a.out_ids[row * a.k + j] = li[j];
+                a.out_vals[row * a.k + j] = key_float(lk[j]);
+            }
+    }
+}
+
 int choose_splits(int64_t rows, int64_t N, int k)
 {
     // aim for >= 8192 waves (256 CUs x 32) while keeping segments long enough to amortise the list
@@ -314,6 +416,20 @@ int launch_topk_rows(const float* scores, int64_t rows, int64_t N, int64_t ld, i
     RECO_REQUIRE(N < (1ll << 32) - 1, "topk: row too long");
     RECO_REQUIRE(scores && out_ids && out_vals, "topk: null pointer");
     TopkArgs a{scores, rows, N, ld, k, exclude, ld_ex, 1, 0, nullptr, out_ids, out_vals};
+    if (!exclude && k <= 16 && N <= 512 && rows >= 32768) {        // many short rows: a lane per row (topk_lane_kernel)
+        const int64_t lblocks = ceil_div64(rows, 256);
+        RECO_REQUIRE(lblocks < (1ll << 31), "topk grid too large");
+        const bool v4 = ld % 4 == 0 && (uintptr_t)scores % 16 == 0;
+        if (k <= 10) {
+            if (v4) hipLaunchKernelGGL((topk_lane_kernel<10, 4>), dim3((unsigned)lblocks), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((topk_lane_kernel<10, 1>), dim3((unsigned)lblocks), dim3(256), 0, s, a);
+        } else {
+            if (v4) hipLaunchKernelGGL((topk_lane_kernel<16, 4>), dim3((unsigned)lblocks), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((topk_lane_kernel<16, 1>), dim3((unsigned)lblocks), dim3(256), 0, s, a);
+        }
+        RECO_CHECK_LAUNCH();
+        return RECO_OK;
+    }
     a.splits = choose_splits(rows, N, k);
     if (a.splits > 1) {
         const size_t need = (size_t)rows * a.splits * k * sizeof(u64);

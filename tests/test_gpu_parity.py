@@ -383,3 +383,24 @@ def test_tower_random_request_sweep(g2, tag, tower_precision):
         oid, oval = O.topk_rows(want, k)
         assert np.array_equal(ids.cpu().numpy(), oid), "%s trial %d ids (k=%d)" % (tag, trial, k)
         assert np.array_equal(vals.cpu().numpy(), oval), "%s trial %d scores" % (tag, trial)
+
+
+def test_topk_many_short_rows_lane_kernel():
+    """>= 32,768 short rows take the lane-per-row kernel (the 99-negative protocol shape): every row length class around the
+    32-column staging slab, k on both register-list sizes, aligned and unaligned leading dimensions, ties, NaN / inf / -0.0."""
+    from recommender_amd import ops
+    rng = np.random.default_rng(5)
+    for case, (rows, N, k, pad) in enumerate(((40000, 100, 10, 0), (33000, 37, 3, 0), (32768, 130, 16, 2), (35001, 31, 10, 1),
+                                              (32769, 64, 11, 0), (33333, 512, 1, 0), (34000, 16, 16, 3))):
+        full = rng.standard_normal((rows, N + pad)).astype(np.float32)
+        if case % 2:
+            full = np.round(full * 2) / 2                        # heavy ties: the lower position must win
+        full[7, :3] = [np.nan, np.inf, -np.inf]
+        full[8, :N] = 0.0
+        full[8, min(2, N - 1)] = -0.0                           # equal to +0.0: position decides
+        t = torch.from_numpy(full).cuda()[:, :N]
+        ids, vals = ops.topk_rows(t, k)
+        oid, oval = O.topk_rows(full[:, :N], k)
+        assert np.array_equal(ids.cpu().numpy(), oid), (rows, N, k, pad)
+        got = vals.cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(oval)) and np.array_equal(np.nan_to_num(got), np.nan_to_num(oval)), (rows, N, k, pad)
