@@ -12,7 +12,7 @@
 // key  (order-preserving float bits << 32) | ~position, so "descending score, ascending position
 // among equals" is a single unsigned compare and ties are deterministic.  An element
 // enters the list only if its key beats the current K-th key (one v_cmp + ballot per 64 elements in
-// the steady state: the kernel is HBM-bound, 4 N bytes per row); a chunk with many entrants is bitonic-sorted across the
+// the steady state: the kernel is HBM-bound, 4 N bytes per row); entrants are collected 64 at a time, bitonic-sorted across the
 // wave and merged with the list instead of being inserted one by one.  Long rows are split over several
 // waves; a second launch merges the per-segment lists the same way.
 #include "reco_common.h"
@@ -136,30 +136,67 @@ struct WaveList {
     }
 };
 
-// A chunk of up to 64 candidate keys.  Few candidates above the current k-th key (the steady state of a long row): serial
-// inserts.  Many (the first chunks of a row or of a merge, adversarially ascending rows): sort the chunk across the wave
-// and merge the two sorted lists, 27-28 shuffle stages whatever the count.
-constexpr int SERIAL_INSERTS_MAX = 8;
+// Candidates are not inserted as they appear: keys that beat the current k-th key are compacted into a per-wave PENDING
+// register (lane r = r-th pending key, ds_permute push) and only when 64 are pending -- or the row segment ends -- are they
+// bitonic-sorted across the wave and merged with the list as two sorted sequences (27-28 shuffle stages whatever the count;
+// a handful of keys are inserted serially instead).  A serial insert costs ~40 instructions per key and slot; batched, an
+// entrant costs ~5.  The threshold is the k-th key as of the last flush, so a few more keys than strictly necessary are
+// collected; the merge drops them.
+constexpr int SERIAL_INSERTS_MAX = 4;
+
+__device__ __forceinline__ u64 permute_push64(u64 v, int dst_lane)      // lane dst_lane receives v (a bijection of lanes)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_permute(dst_lane << 2, (int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_permute(dst_lane << 2, (int)(uint32_t)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+
+struct Pending {
+    u64 key;     // lanes [0, n) hold pending keys, the others 0
+    int n;       // wave-uniform
+    __device__ __forceinline__ void clear() { key = 0; n = 0; }
+};
 
 template <int SLOTS>
-__device__ __forceinline__ void offer(WaveList<SLOTS>& L, u64 key, bool valid, u64& thr, int k, int lane)
+__device__ __forceinline__ void flush(WaveList<SLOTS>& L, Pending& P, u64& thr, int k, int lane)
 {
-    const bool cand = valid && key > thr;
-    u64 m = __ballot(cand);
-    if (__popcll(m) > SERIAL_INSERTS_MAX) {
-        L.merge_sorted(wave_sort_desc(cand ? key : 0, lane), lane);
-        thr = L.kth(k);
-        return;
-    }
-    while (m) {
-        const int src = __ffsll((long long)m) - 1;
-        const u64 x = bcast(key, src);
-        m &= m - 1;
-        if (x > thr) {               // thr may have risen since the ballot
-            L.insert(x, lane);
-            thr = L.kth(k);
+    if (P.n == 0) return;
+    if (P.n <= SERIAL_INSERTS_MAX) {
+        for (int i = 0; i < P.n; ++i) {
+            const u64 x = bcast(P.key, i);
+            if (x > thr) {               // thr may have risen since the key was collected
+                L.insert(x, lane);
+                thr = L.kth(k);
+            }
         }
+    } else {
+        L.merge_sorted(wave_sort_desc(P.key, lane), lane);
+        thr = L.kth(k);
     }
+    P.clear();
+}
+
+template <int SLOTS>
+__device__ __forceinline__ void offer(WaveList<SLOTS>& L, Pending& P, u64 key, bool valid, u64& thr, int k, int lane)
+{
+    bool cand = valid && key > thr;
+    u64 m = __ballot(cand);
+    int c = __popcll(m);
+    if (c == 0) return;
+    if (P.n + c > 64) {
+        flush<SLOTS>(L, P, thr, k, lane);
+        cand = cand && key > thr;
+        m = __ballot(cand);
+        c = __popcll(m);
+        if (c == 0) return;
+    }
+    // candidates go to lanes n .. n + c - 1 in lane order; the other lanes push a zero to the remaining lanes (mod 64), so the
+    // permutation is a bijection and no lane is targeted twice
+    const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    const int dst = cand ? P.n + below : ((P.n + c + (lane - below)) & 63);
+    const u64 got = permute_push64(cand ? key : 0, dst);
+    if (lane >= P.n && lane < P.n + c) P.key = got;
+    P.n += c;
 }
 
 struct TopkArgs {
@@ -192,34 +229,41 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(TopkArgs a)
 
     WaveList<SLOTS> L;
     L.clear();
+    Pending P;
+    P.clear();
     u64 thr = 0;
     if constexpr (VEC == 4) {
         constexpr int UN = 2;
-        for (int64_t base = s0; base < s1; base += 256 * UN) {
-            f32x4 v[UN];
-            int64_t n0[UN];
+        auto load = [&](int64_t base, f32x4* v) {
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                n0[u] = base + u * 256 + 4 * lane;
+                const int64_t n0 = base + u * 256 + 4 * lane;
                 v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (n0[u] + 3 < s1) v[u] = *reinterpret_cast<const f32x4*>(src + n0[u]);
+                if (n0 + 3 < s1) v[u] = *reinterpret_cast<const f32x4*>(src + n0);
                 else {
-                    if (n0[u] + 0 < s1) v[u].x = src[n0[u] + 0];
-                    if (n0[u] + 1 < s1) v[u].y = src[n0[u] + 1];
-                    if (n0[u] + 2 < s1) v[u].z = src[n0[u] + 2];
+                    if (n0 + 0 < s1) v[u].x = src[n0 + 0];
+                    if (n0 + 1 < s1) v[u].y = src[n0 + 1];
+                    if (n0 + 2 < s1) v[u].z = src[n0 + 2];
                 }
             }
+        };
+        f32x4 v[UN], vn[UN];
+        load(s0, v);
+        for (int64_t base = s0; base < s1; base += 256 * UN) {
+            if (base + 256 * UN < s1) load(base + 256 * UN, vn);       // next iteration's loads fly under this one's compares
 #pragma unroll
             for (int u = 0; u < UN; ++u)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const int64_t n = n0[u] + t;
+                    const int64_t n = base + u * 256 + 4 * lane + t;
                     const bool ok = n < s1;
                     float x = v[u][t];
                     if (ex && ok && ex[n]) x = x * 0.f - 1e10f;   // helper.py:313: pred*(~seen) - seen*1e10
                     const u64 key = ((u64)float_key(x) << 32) | (uint32_t)~(uint32_t)n;
-                    offer<SLOTS>(L, key, ok, thr, a.k, lane);
+                    offer<SLOTS>(L, P, key, ok, thr, a.k, lane);
                 }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) v[u] = vn[u];
         }
     } else {
         for (int64_t base = s0; base < s1; base += 256) {
@@ -236,10 +280,11 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(TopkArgs a)
             for (int t = 0; t < 4; ++t) {
                 const int64_t n = base + t * 64 + lane;
                 const u64 key = ((u64)float_key(v[t]) << 32) | (uint32_t)~(uint32_t)n;
-                offer<SLOTS>(L, key, ok[t], thr, a.k, lane);
+                offer<SLOTS>(L, P, key, ok[t], thr, a.k, lane);
             }
         }
     }
+    flush<SLOTS>(L, P, thr, a.k, lane);
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         const int r = s * 64 + lane;
