@@ -432,8 +432,10 @@ __global__ __launch_bounds__(256) void topk_lane_kernel(TopkArgs a)
 
 int choose_splits(int64_t rows, int64_t N, int k)
 {
-    // aim for >= 8192 waves (256 CUs x 32) while keeping segments long enough to amortise the list
-    int64_t want = ceil_div64(8192, rows);
+    // aim for >= 4096 waves (4 per SIMD) while keeping segments long enough to amortise the list: every segment pays its own
+    // k ln(segment / k) entrants, so fewer, longer segments do less work (256 x 1M, k = 100: 0.39 ms at 8192 waves, 0.35 ms at
+    // 4096, 0.53 ms at 2048 where the loads are no longer hidden)
+    int64_t want = ceil_div64(4096, rows);
     int64_t max_by_len = N / 4096 > 0 ? N / 4096 : 1;
     int64_t s = want < max_by_len ? want : max_by_len;
     if (s < 1) s = 1;
