@@ -200,24 +200,49 @@ __device__ __forceinline__ void pair_stage_load(const PairArgs& a, int64_t base,
         my_u = clamp_id(a.user ? a.user[b] : b, a.n_users, h == 0 ? a.oob : nullptr);
         my_i = clamp_id(a.item ? a.item[b] : b, a.n_items, h == 0 ? a.oob : nullptr);
     }
+    // Pair lists often come in runs of one user (the 99-negative protocol: 100 candidates per user, inference_engine
+    // predict_batch: one user): when all 32 pairs of the group share their user, the user's rows are loaded ONCE (one float4
+    // per lane) instead of 32 times -- 40 % of the group's L2 traffic.  Wave-uniform test, identical results.
+    const int64_t u_first = __shfl(my_u, 0);
+    const bool one_user = __ballot(my_u != u_first) == 0;
+    if (one_user) {
+        const f32x4 prow = reinterpret_cast<const f32x4*>(a.P + u_first * H1)[j];
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int pl = it * 2 + h;
-        const int64_t u = __shfl(my_u, pl);
-        const int64_t i = __shfl(my_i, pl);
-        st.p[it] = reinterpret_cast<const f32x4*>(a.P + u * H1)[j];
-        st.q[it] = reinterpret_cast<const f32x4*>(a.Q + i * H1)[j];
+        for (int it = 0; it < 16; ++it) {
+            st.p[it] = prow;
+            st.q[it] = reinterpret_cast<const f32x4*>(a.Q + __shfl(my_i, it * 2 + h) * H1)[j];
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int pl = it * 2 + h;
+            const int64_t u = __shfl(my_u, pl);
+            const int64_t i = __shfl(my_i, pl);
+            st.p[it] = reinterpret_cast<const f32x4*>(a.P + u * H1)[j];
+            st.q[it] = reinterpret_cast<const f32x4*>(a.Q + i * H1)[j];
+        }
     }
     if constexpr (G > 0) {
         constexpr int C = G / 4;
+        static_assert(64 % C == 0, "a lane keeps one float4 column of the GMF rows across the stage registers");
+        if (one_user) {
+            const f32x4 grow = reinterpret_cast<const f32x4*>(a.EUg + u_first * G)[lane % C];
 #pragma unroll
-        for (int it = 0; it < PairStage<G>::NG; ++it) {
-            const int e = it * 64 + lane;
-            const int pl = e / C, c = e % C;
-            const int64_t u = __shfl(my_u, pl);
-            const int64_t i = __shfl(my_i, pl);
-            st.gu[it] = reinterpret_cast<const f32x4*>(a.EUg + u * G)[c];
-            st.gi[it] = reinterpret_cast<const f32x4*>(a.EIg + i * G)[c];
+            for (int it = 0; it < PairStage<G>::NG; ++it) {
+                const int e = it * 64 + lane;
+                st.gu[it] = grow;                                   // e % C == lane % C: 64 is a multiple of C
+                st.gi[it] = reinterpret_cast<const f32x4*>(a.EIg + __shfl(my_i, e / C) * G)[e % C];
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < PairStage<G>::NG; ++it) {
+                const int e = it * 64 + lane;
+                const int pl = e / C, c = e % C;
+                const int64_t u = __shfl(my_u, pl);
+                const int64_t i = __shfl(my_i, pl);
+                st.gu[it] = reinterpret_cast<const f32x4*>(a.EUg + u * G)[c];
+                st.gi[it] = reinterpret_cast<const f32x4*>(a.EIg + i * G)[c];
+            }
         }
     }
 }
