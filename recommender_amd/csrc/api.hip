@@ -240,6 +240,7 @@ extern "C" int reco_tower_create(const reco_tower_desc_t* d, void* stream, reco_
     RECO_REQUIRE(d->dg >= 0 && d->dm >= 0 && (d->dg > 0 || d->dm > 0), "tower_create: model has neither GMF nor MLP branch");
     RECO_REQUIRE(d->dg % 4 == 0 && d->dm % 4 == 0, "tower_create: dg=%d / dm=%d must be multiples of 4", d->dg, d->dm);
     RECO_REQUIRE(d->n_users >= 0 && d->n_items >= 0, "tower_create: negative table size");
+    RECO_REQUIRE(d->n_users < (1ll << 31) && d->n_items < (1ll << 31), "tower_create: tables of 2^31 rows or more are not supported");
     RECO_REQUIRE(d->w_predict && d->b_predict, "tower_create: predict layer missing");
     RECO_REQUIRE(d->act == RECO_ACT_NONE || d->act == RECO_ACT_RATING, "tower_create: act must be NONE or RATING");
     RECO_REQUIRE(d->precision == RECO_PREC_F32 || d->precision == RECO_PREC_SPLIT_BF16X3,

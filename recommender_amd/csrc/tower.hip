@@ -102,6 +102,7 @@ __device__ __forceinline__ float tower_mlp_part(const float* s_img, int lane, X1
         auto xraw = r0;                         // (type only: overwritten below whenever it is used)
         f32x4 a0n = a0, a1n = a1;
         if (q + 1 < 16) {                       // issue quad q+1's three ds_read_b128 first ...
+            x1.pre(q + 1);                      // (pair kernel: the second K half is staged before quad 8 is read)
             xraw = x1.raw(q + 1);
 #ifndef RECO_ABL_NO_W2_READS
             a0n = w2[(q + 1) * 64];
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
                     {
                         return PQ{*reinterpret_cast<const f32x4*>(qrow + 8 * q), *reinterpret_cast<const f32x4*>(prow + 8 * q)};
                     }
+                    __device__ __forceinline__ void pre(int) const {}
                     __device__ __forceinline__ f32x4 finish(int, const PQ& v) const { return relu4(v.p + v.q); }
                     __device__ __forceinline__ f32x4 passthrough(const PQ& v) const { return v.q; }
                 };
@@ -298,11 +300,17 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
 #endif
 }
 
-template <int G, bool L3>
-__global__ __launch_bounds__(256, 1) void tower_pairs_kernel(PairArgs a)
+// Pair-list kernel.  WAVES waves share the weight image; every wave is private otherwise (no workgroup barrier in the loop):
+// 32 pairs at a time, the rows of the NEXT group in flight in registers while the MFMAs of the current one run out of the wave's
+// LDS staging area.  The layer-1 activations are staged one K half at a time (tower_shared.h): the first half before quad 0,
+// the second -- into the same 8.7 KB -- right before quad 8 is read (LDS operations of one wave execute in issue order, so the
+// overwrite needs no barrier).  With half rows 8 waves fit next to the image (148 KB): 2 waves per SIMD.
+template <int G, bool L3, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_kernel(PairArgs a)
 {
     constexpr int GS = G + 4;
-    constexpr int WAVE_FLOATS = 32 * QS + (G > 0 ? 32 * GS : 0);
+    constexpr int WAVE_FLOATS = 32 * HS + (G > 0 ? 32 * GS : 0);
+    constexpr int NG = G > 0 ? (32 * (G / 4)) / 64 : 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_img = smem;
 
@@ -310,31 +318,61 @@ __global__ __launch_bounds__(256, 1) void tower_pairs_kernel(PairArgs a)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
-    float* s_x = smem + IMG_SIZE + wave * WAVE_FLOATS;   // [32][QS]  relu(P+Q) of this wave's pairs
-    float* s_gp = s_x + 32 * QS;                          // [32][GS]  gmf products
+    float* s_x = smem + IMG_SIZE + wave * WAVE_FLOATS;   // [32][HS]  relu(P+Q), one K half of this wave's pairs
+    float* s_gp = s_x + 32 * HS;                          // [32][GS]  gmf products
 
-    for (int i = tid; i < IMG_SIZE / 4; i += 256)
+    for (int i = tid; i < IMG_SIZE / 4; i += 64 * WAVES)
         reinterpret_cast<f32x4*>(s_img)[i] = reinterpret_cast<const f32x4*>(a.img)[i];
     __syncthreads();
 
     const int64_t ngroups = (a.B + 31) / 32;
-    const int64_t stride = (int64_t)gridDim.x * 4;
-    int64_t grp = (int64_t)blockIdx.x * 4 + wave;
-    PairStage<G> st;
-    if (grp < ngroups) pair_stage_load<G>(a, grp * 32, lane, st);
+    const int64_t stride = (int64_t)gridDim.x * WAVES;
+    int64_t grp = (int64_t)blockIdx.x * WAVES + wave;
+    f32x4 pf[8], qf[8], ps[8], qs[8];                     // first / second K half of the next group's P and Q rows
+    f32x4 gu[NG], gi[NG];
+    int nu = 0, ni = 0;                                   // the next group's ids (lanes 0..31)
+    if (grp < ngroups) {
+        pair_ids(a, grp * 32, lane, nu, ni);
+        pair_load_half(a, nu, ni, lane, 0, pf, qf);
+        pair_load_half(a, nu, ni, lane, 1, ps, qs);
+        if constexpr (G > 0) pair_load_gmf<G>(a, nu, ni, lane, gu, gi);
+    }
     for (; grp < ngroups; grp += stride) {
         const int64_t base = grp * 32;
-        pair_stage_store<G>(s_x, s_gp, lane, st);
+        const bool more = grp + stride < ngroups;
+        pair_store_half(s_x, lane, pf, qf);
+        if constexpr (G > 0) pair_store_gmf<G>(s_gp, lane, gu, gi);
         __builtin_amdgcn_wave_barrier();
-        if (grp + stride < ngroups) pair_stage_load<G>(a, (grp + stride) * 32, lane, st);   // in flight under the MFMAs
-        const float* xrow = s_x + j * QS + 4 * h;
+        // the second half (ps / qs) still belongs to THIS group: the next group's ids wait in other registers until it is stored
+        int nu2 = 0, ni2 = 0;
+        if (more) {
+            pair_ids(a, (grp + stride) * 32, lane, nu2, ni2);
+            pair_load_half(a, nu2, ni2, lane, 0, pf, qf);                  // in flight under the MFMAs
+            if constexpr (G > 0) pair_load_gmf<G>(a, nu2, ni2, lane, gu, gi);
+        }
+        const float* xrow = s_x + j * HS + 4 * h;
         struct X1Pair {
+            const PairArgs& a;
             const float* xrow;
-            __device__ __forceinline__ f32x4 raw(int q) const { return *reinterpret_cast<const f32x4*>(xrow + 8 * q); }
+            float* s_x;
+            f32x4* ps;
+            f32x4* qs;
+            int nu, ni;
+            int lane;
+            bool more;
+            __device__ __forceinline__ void pre(int q) const
+            {
+                if (q == 8) {                 // quads 0..7 have all been read: stage the second half, refill its registers
+                    pair_store_half(s_x, lane, ps, qs);
+                    __builtin_amdgcn_wave_barrier();
+                    if (more) pair_load_half(a, nu, ni, lane, 1, ps, qs);
+                }
+            }
+            __device__ __forceinline__ f32x4 raw(int q) const { return *reinterpret_cast<const f32x4*>(xrow + 8 * (q & 7)); }
             __device__ __forceinline__ f32x4 finish(int, f32x4 v) const { return v; }
             __device__ __forceinline__ f32x4 passthrough(f32x4 v) const { return v; }
         };
-        float part = tower_mlp_part<L3>(s_img, lane, X1Pair{xrow});
+        float part = tower_mlp_part<L3>(s_img, lane, X1Pair{a, xrow, s_x, ps, qs, nu2, ni2, lane, more});
         if constexpr (G > 0) {
             const float* grow = s_gp + j * GS + h * (G / 2);
             const float* wpg = s_img + IMG_WPG + h * (G / 2);
@@ -479,12 +517,15 @@ int launch_tile_t(const TileArgs& a, hipStream_t s)
 template <int G, bool L3>
 int launch_pairs_t(const PairArgs& a, hipStream_t s)
 {
-    constexpr size_t lds = (size_t)(IMG_SIZE + 4 * (32 * QS + (G > 0 ? 32 * (G + 4) : 0))) * sizeof(float);
+    // 8 waves per workgroup when their half-row staging areas fit next to the image (G <= 32: 148 KB), else 4
+    constexpr int WAVES = G <= 32 ? 8 : 4;
+    constexpr size_t lds = (size_t)(IMG_SIZE + WAVES * (32 * HS + (G > 0 ? 32 * (G + 4) : 0))) * sizeof(float);
+    static_assert(lds <= 160 * 1024, "pair kernel LDS budget");
     static bool attr[RECO_MAX_DEVICES] = {};
-    if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&tower_pairs_kernel<G, L3>), lds, attr)) return rc;
-    const int64_t nchunks = ceil_div64(a.B, 128);
-    const unsigned grid = (unsigned)(nchunks < 256 ? nchunks : 256);   // persistent: one 4-wave workgroup per CU
-    hipLaunchKernelGGL((tower_pairs_kernel<G, L3>), dim3(grid), dim3(256), lds, s, a);
+    if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&tower_pairs_kernel<G, L3, WAVES>), lds, attr)) return rc;
+    const int64_t nchunks = ceil_div64(a.B, 32 * WAVES);
+    const unsigned grid = (unsigned)(nchunks < 256 ? nchunks : 256);   // persistent: one workgroup per CU
+    hipLaunchKernelGGL((tower_pairs_kernel<G, L3, WAVES>), dim3(grid), dim3(64 * WAVES), lds, s, a);
     RECO_CHECK_LAUNCH();
     return RECO_OK;
 }

@@ -264,4 +264,74 @@ __device__ __forceinline__ void pair_stage_store(float* s_x, float* s_gp, int la
     }
 }
 
+// ---- half-row staging for the exact pair kernel -------------------------------------------------------------------------
+// The layer-1 activations of a group are staged one K half (64 of 128 features) at a time: [32 pairs][HS] per wave, 8.7 KB
+// instead of 16.9 KB, so that 8 waves share one weight image in LDS (2 waves per SIMD).  Register group `it` (0..7) of a half
+// holds float4 column c = lane & 15 of rows 4 it + (lane >> 4): a wave instruction reads 4 rows x 256 contiguous bytes.
+constexpr int HS = 64 + 4;     // padded LDS row stride of a half row: conflict-free ds_read_b128 by 8 rows
+
+// ids are carried as int32 (tables have fewer than 2^31 rows, checked in reco_tower_create): one ds_bpermute per shuffle
+__device__ __forceinline__ void pair_ids(const PairArgs& a, int64_t base, int lane, int& my_u, int& my_i)
+{
+    const int j = lane & 31, h = lane >> 5;
+    my_u = 0; my_i = 0;           // ids of the 32 pairs live in lanes 0..31 (mirrored in 32..63)
+    const int64_t b = base + j;
+    if (b < a.B) {
+        my_u = (int)clamp_id(a.user ? a.user[b] : b, a.n_users, h == 0 ? a.oob : nullptr);
+        my_i = (int)clamp_id(a.item ? a.item[b] : b, a.n_items, h == 0 ? a.oob : nullptr);
+    }
+}
+
+__device__ __forceinline__ void pair_load_half(const PairArgs& a, int my_u, int my_i, int lane, int half, f32x4* p, f32x4* q)
+{
+    const int c = 16 * half + (lane & 15), r = lane >> 4;
+    const int u_first = __shfl(my_u, 0);
+    if (__ballot(my_u != u_first) == 0) {            // the whole group is one user: its row once (see pair_stage_load)
+        const f32x4 prow = reinterpret_cast<const f32x4*>(a.P + (int64_t)u_first * H1)[c];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            p[it] = prow;
+            q[it] = reinterpret_cast<const f32x4*>(a.Q + (int64_t)__shfl(my_i, 4 * it + r) * H1)[c];
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            p[it] = reinterpret_cast<const f32x4*>(a.P + (int64_t)__shfl(my_u, 4 * it + r) * H1)[c];
+            q[it] = reinterpret_cast<const f32x4*>(a.Q + (int64_t)__shfl(my_i, 4 * it + r) * H1)[c];
+        }
+    }
+}
+
+__device__ __forceinline__ void pair_store_half(float* s_x, int lane, const f32x4* p, const f32x4* q)
+{
+    const int c = lane & 15, r = lane >> 4;
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+        *reinterpret_cast<f32x4*>(s_x + (4 * it + r) * HS + 4 * c) = relu4(p[it] + q[it]);
+}
+
+template <int G>
+__device__ __forceinline__ void pair_load_gmf(const PairArgs& a, int my_u, int my_i, int lane, f32x4* gu, f32x4* gi)
+{
+    constexpr int C = G / 4, NG = (32 * C) / 64;
+    static_assert(64 % C == 0, "a lane keeps one float4 column of the GMF rows across the stage registers");
+#pragma unroll
+    for (int it = 0; it < NG; ++it) {
+        const int e = it * 64 + lane;
+        gu[it] = reinterpret_cast<const f32x4*>(a.EUg + (int64_t)__shfl(my_u, e / C) * G)[e % C];
+        gi[it] = reinterpret_cast<const f32x4*>(a.EIg + (int64_t)__shfl(my_i, e / C) * G)[e % C];
+    }
+}
+
+template <int G>
+__device__ __forceinline__ void pair_store_gmf(float* s_gp, int lane, const f32x4* gu, const f32x4* gi)
+{
+    constexpr int C = G / 4, NG = (32 * C) / 64;
+#pragma unroll
+    for (int it = 0; it < NG; ++it) {
+        const int e = it * 64 + lane;
+        *reinterpret_cast<f32x4*>(s_gp + (e / C) * (G + 4) + 4 * (e % C)) = gu[it] * gi[it];
+    }
+}
+
 }  // namespace
