@@ -1,20 +1,30 @@
 #!/usr/bin/env python3
-"""Headline benchmark: NeuMF full-catalog scoring + top-10 (BASELINE.json configs[1]) on N MI355X.
+"""Headline benchmark: NeuMF full-catalog scoring + top-k on N MI355X (BASELINE.json configs[1] and configs[4]).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One step = one pass of the hot path over one batch: every rank scores its 6,038 users against the
-3,533-item catalog (21,332,254 pairs: layer-1 projections + fused tower + top-10 select), then all ranks
-all-gather the top-10 lists over RCCL (one packed message; the gather of step i overlaps the kernels of step i + 1, and the
-last gather is inside the timed region).  Weights: NeuMF-end random init (reference constructor order,
-torch.manual_seed(0)); at N > 1 the user table has N x 6,038 rows, replicated, user-sharded (weak scaling).
-Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+Both forms work for every N: typed plainly with N > 1, this process starts the N ranks itself (a child
+`python -m torch.distributed.run`, before anything here touches the GPU) and relays rank 0's line.
+
+Two workloads, both at every N (user-sharded, tables replicated, weak scaling: per-GPU work is fixed):
+  * `value` -- cfg2: every rank scores its 6,038 users against the 3,533-item catalog (21,332,254 pairs: layer-1
+    projections + fused tower + top-10 select) per step, then all ranks all-gather the top-10 lists over RCCL (one packed
+    message; the gather of step i overlaps the kernels of step i + 1, and the last gather is inside the timed region).
+    Weights: NeuMF-end random init (reference constructor order, torch.manual_seed(0)); at N > 1 the user table has
+    N x 6,038 rows.  K steps after W warm-up steps, barrier + synchronize on both sides, max over ranks.
+  * `cfg5_top100` -- the second half of the metric: synthetic NeuMF 10 M users x 1 M items, full-catalog top-100 users/s;
+    every rank scores a 1,024-user slice per step (1.024e9 pairs) and the top-100 lists are all-gathered.  Same timing
+    protocol, its own step count (--cfg5-steps).  Runs after the cfg2 region.
+Inputs are resident in HBM before the timed regions.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes
 import json
 import os
+import signal
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,11 +37,107 @@ import torch.distributed as dist  # noqa: E402
 
 N_USERS, N_ITEMS, FACTOR, LAYERS, K = 6038, 3533, 32, 3, 10
 FLOP_PER_PAIR = 2 * (256 * 128 + 128 * 64 + 64 * 32) + 32 + 2 * 64          # 86,176 algorithmic
-FLOP_PER_PAIR_EXEC = 2 * (128 * 64 + 64 * 32) + 32 + 2 * 64 + 128          # 20,896 executed by the tile kernel: MFMA layers 2-3,
+FLOP_PER_PAIR_EXEC = 2 * (128 * 64 + 64 * 32) + 32 + 2 * 64 + 128          # 20,768 executed by the tile kernel: MFMA layers 2-3,
 #                                                                              GMF, predict, and the layer-1 add (factorised layer 1)
 PEAK_F32_MFMA_TFLOPS = 157.3                                                # MI355X_MICROARCH.md chip-level parameters
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cfg5", action="store_true", help="skip the synthetic 10M x 1M top-100 slice (field cfg5_top100)")
+    ap.add_argument("--cfg5", action="store_true", help=argparse.SUPPRESS)      # accepted for older command lines: now the default
+    ap.add_argument("--cfg5-steps", type=int, default=3)
+    ap.add_argument("--cfg5-users-per-gpu", type=int, default=1024)
+    ap.add_argument("--no-split", action="store_true", help="skip the opt-in bf16x3 mode's figures (field split_bf16x3)")
+    ap.add_argument("--share-gpus", action="store_true",
+                    help="REHEARSAL ONLY: run the N ranks on however many GPUs are visible (ranks share devices, gloo backend "
+                         "because RCCL refuses two ranks on one device); checks the N > 1 code path on a 1-GPU box, the numbers "
+                         "mean nothing")
+    ap.add_argument("--launch-timeout", type=float, default=600.0, help="seconds before the self-started ranks are taken to be hung")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` with N > 1 and no torchrun environment
+# ---------------------------------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher_argv(argv, gpus, port):
+    """Command line of the child that runs the N ranks: the driver's own launch form around this script's arguments."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def _run_children(cmd, env, timeout_s):
+    """Runs cmd in its own process group; returns (exit code or None on timeout, stdout text)."""
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=timeout_s)
+        return proc.returncode, out.decode(errors="replace")
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)          # exactly the group started above
+        except ProcessLookupError:
+            pass
+        out, _ = proc.communicate()
+        return None, out.decode(errors="replace")
+
+
+def _result_line(text):
+    for line in reversed(text.splitlines()):
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            try:
+                json.loads(line)
+                return line
+            except ValueError:
+                continue
+    return None
+
+
+def self_launch(args, argv):
+    """Parent of a plain `bench.py --gpus N`: never initialises the GPU, starts the ranks, relays rank 0's JSON line.
+
+    A run whose ranks fail or hang with the overlapped gather is repeated once, in fresh processes, with one blocking
+    all-gather per step (RECO_BENCH_SYNC_GATHER=1): a hang cannot be recovered from inside the hung process."""
+    visible = torch.cuda.device_count()                   # counting devices does not initialise the GPU
+    if visible < args.gpus and not args.share_gpus:
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) are visible (use --share-gpus to rehearse the N-rank path on "
+                         "fewer devices)" % (args.gpus, visible))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    if os.environ.get("RECO_BENCH_DRY_LAUNCH") == "1":    # CPU test of the launcher: print the command, start nothing
+        print(json.dumps({"launcher_argv": launcher_argv(argv, args.gpus, 29500)}))
+        return 0
+    attempts = [("overlapped", {})]
+    if os.environ.get("RECO_BENCH_SYNC_GATHER", "0") != "1":
+        attempts.append(("blocking", {"RECO_BENCH_SYNC_GATHER": "1", "RECO_BENCH_FELL_BACK": "1"}))
+    for mode, extra in attempts:
+        cmd = launcher_argv(argv, args.gpus, free_port())
+        rc, out = _run_children(cmd, dict(env, **extra), args.launch_timeout)
+        line = _result_line(out)
+        if rc == 0 and line:
+            sys.stdout.write(line + "\n")
+            sys.stdout.flush()
+            return 0
+        print("bench.py: the %d self-started ranks %s with the %s gather%s" % (
+            args.gpus, "timed out after %.0f s" % args.launch_timeout if rc is None else "exited with code %s" % rc, mode,
+            "; repeating with one blocking all-gather per step" if (mode, extra) != attempts[-1] else ""), file=sys.stderr, flush=True)
+    return 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------------------------------
 def build_model(n_users, device):
     from recommender_amd.helpers import NCF
     torch.manual_seed(0)
@@ -81,29 +187,40 @@ def cpu_baseline(model, check_ids, check_vals, budget_s=12.0, budget_1t_s=5.0):
 
 
 def measured_traffic(kernel_substr):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, guide's gfx950 correction)."""
-    best = None
+    """(HBM bytes per launch of the dominant kernel, file it was read from): FETCH_SIZE x2 + WRITE_SIZE from the committed
+    rocprofv3 --pmc passes of this same command (the guide's gfx950 correction).  PMC counters need the profiler: they cannot be
+    read from inside the run, so the figure is labelled with its source."""
+    best = (None, None)
     pdir = os.path.join(ROOT, "profiles")
     for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
         if f.endswith("_hbm_traffic.json"):
             for name, v in json.load(open(os.path.join(pdir, f)))["kernels"].items():
                 if kernel_substr in name and "hbm_bytes_per_launch_corrected" in v:
-                    best = v["hbm_bytes_per_launch_corrected"]
+                    best = (v["hbm_bytes_per_launch_corrected"], "profiles/" + f)
     return best
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cfg5", action="store_true",
-                    help="also time the synthetic 10M x 1M top-100 slice (second half of the metric, field cfg5_top100); off by "
-                         "default so that the default command's rocprofv3 kernel statistics cover the cfg2 launches only")
-    ap.add_argument("--no-cfg5", action="store_true", help=argparse.SUPPRESS)   # accepted for older command lines
-    args = ap.parse_args()
+def mfma_roofline(kernel, pairs_per_launch, kernel_ms, launches, traffic=None, traffic_source=None, algorithmic_bytes=None):
+    """roofline object for a tower kernel: `achieved` / `frac` count the FLOPs the kernel EXECUTES (hardware utilisation, <= 1);
+    the reference's algorithmic 86,176 FLOP/pair (layer 1 is factorised away) sits under `algorithmic`."""
+    executed = pairs_per_launch * FLOP_PER_PAIR_EXEC / (kernel_ms * 1e-3) / 1e12
+    algorithmic = pairs_per_launch * FLOP_PER_PAIR / (kernel_ms * 1e-3) / 1e12
+    r = {"bound": "mfma", "kernel": kernel, "achieved": executed, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+         "frac": executed / PEAK_F32_MFMA_TFLOPS, "flop_per_pair_executed": FLOP_PER_PAIR_EXEC,
+         "kernel_ms": kernel_ms, "launches_timed": launches, "pairs_per_launch": pairs_per_launch,
+         "algorithmic": {"flop_per_pair": FLOP_PER_PAIR, "tflops": algorithmic, "ratio_to_peak": algorithmic / PEAK_F32_MFMA_TFLOPS,
+                         "note": "the reference's FLOP count per pair over the fp32 MFMA peak: a speed-up-inclusive ratio (layer 1 is "
+                                 "factorised, W1[u;i] = W1u u + W1i i), NOT a hardware fraction"},
+         "traffic": traffic}
+    if traffic is not None:
+        r["traffic_source"] = traffic_source
+        r["traffic_note"] = "HBM bytes per launch from separate rocprofv3 --pmc passes of this command, not live"
+        if algorithmic_bytes:
+            r["traffic_algorithmic_bytes"] = algorithmic_bytes
+    return r
 
+
+def main_rank(args):
     # stdout carries exactly ONE line, the result: everything else that writes to file descriptor 1 in this process (RCCL prints
     # a version banner there at communicator creation) goes to stderr instead
     sys.stdout.flush()
@@ -114,19 +231,23 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # under torch.distributed.run (also at N = 1)
+    n_dev = torch.cuda.device_count()
+    if args.share_gpus:
+        local = local % max(n_dev, 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # under torch.distributed.run (also at N = 1)
+    backend = "gloo" if args.share_gpus else "nccl"
     if launched:
+        import datetime
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        # a stuck collective ends the ranks (RCCL's watchdog) instead of hanging them; the parent then repeats with the blocking gather
+        kw = {"device_id": device} if backend == "nccl" else {}
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=180), **kw)
 
-    from recommender_amd import _lib
+    from recommender_amd import _lib, ops
     from recommender_amd.dist import TopkGather, shard_range
-
-    from recommender_amd import ops
 
     total_users = N_USERS * world
     model = build_model(total_users, device)
@@ -155,13 +276,13 @@ def main():
             done, self.last = self.last, None
             return done
 
-    gather_mode = {"pipelined": os.environ.get("RECO_BENCH_SYNC_GATHER", "0") != "1"}     # the variable exists to test the fallback
+    pipelined = os.environ.get("RECO_BENCH_SYNC_GATHER", "0") != "1"
 
     def timed_run(precision):
         """W warm-up steps, then K timed steps between fences; (seconds max over ranks, mean ms of the tile kernel, ids, vals)."""
         ops.set_tower_precision(precision)
         # step i's all-gather overlaps step i + 1's kernels
-        pipe = TopkGather(model, K, total_users) if gather_mode["pipelined"] else _SyncGather()
+        pipe = TopkGather(model, K, total_users) if pipelined else _SyncGather()
         for _ in range(args.warmup):
             pipe.step()
         pipe.flush()
@@ -183,65 +304,58 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()), kernel_ms, n.value, ids.clone(), vals.clone()
 
-    # the headline: exact fp32 MFMA (every product the exact fp32 product)
-    try:
-        elapsed, tile_ms, n_timed, ids, vals = timed_run("f32")
-    except Exception as exc:  # noqa: BLE001 -- every rank runs the same code, so every rank lands here together
-        if not launched:
-            raise
-        print("bench: pipelined all-gather failed (%s: %s); falling back to one blocking all-gather per step" % (type(exc).__name__, exc),
-              file=sys.stderr, flush=True)
-        gather_mode["pipelined"] = False
-        _lib.check(L.reco_profile_enable(0))
-        elapsed, tile_ms, n_timed, ids, vals = timed_run("f32")
-    # the same job in the opt-in split-operand mode (fp32 = 3 bf16 pieces on the bf16 MFMA, fp32 accumulate)
-    s_elapsed, s_tile_ms, _, s_ids, s_vals = timed_run("bf16x3")
-    ops.set_tower_precision("f32")
+    # the headline: exact fp32 MFMA (every product the exact fp32 product).  No in-process fallback: a gather that hangs cannot be
+    # recovered from here (GatherTimeout / the watchdog end the rank; self_launch() repeats the run with the blocking gather).
+    elapsed, tile_ms, n_timed, ids, vals = timed_run("f32")
+    split = None
+    if not args.no_split:      # the same job in the opt-in split-operand mode (fp32 = 3 bf16 pieces on the bf16 MFMA, fp32 accumulate)
+        split = timed_run("bf16x3")
+        ops.set_tower_precision("f32")
 
-    # second half of BASELINE.json's metric: full-catalog top-100 users/s on the synthetic 10M x 1M NeuMF (configs[4]),
-    # timed on a slice of 1,024 users per GPU per step (tools/bench_cfg5.py); never allowed to take the headline line down
+    # second half of BASELINE.json's metric: full-catalog top-100 users/s on the synthetic 10M x 1M NeuMF (configs[4]), timed on
+    # a slice of 1,024 users per GPU per step, after the cfg2 region
     cfg5 = None
-    if args.cfg5 and not args.no_cfg5:
-        try:
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            import bench_cfg5
-            cfg5 = {p: bench_cfg5.run(device, world, rank, launched, 1024, 3, 1, p) for p in ("f32", "bf16x3")}
-        except Exception as exc:  # noqa: BLE001
-            cfg5 = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    if not args.no_cfg5:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_cfg5
+        cfg5 = bench_cfg5.run(device, world, rank, launched, args.cfg5_users_per_gpu, args.cfg5_steps, 1, "f32")
+        if not args.no_split:
+            s5 = bench_cfg5.run(device, world, rank, launched, args.cfg5_users_per_gpu, args.cfg5_steps, 1, "bf16x3")
+            if rank == 0:
+                cfg5["split_bf16x3"] = {k: s5[k] for k in ("value", "unit", "pairs_per_s", "ms_per_step", "roofline")}
 
     if rank == 0:
         pairs_per_rank = N_USERS * N_ITEMS
         pairs = pairs_per_rank * world * args.steps
-        achieved = pairs_per_rank * FLOP_PER_PAIR / (tile_ms * 1e-3) / 1e12
-        executed = pairs_per_rank * FLOP_PER_PAIR_EXEC / (tile_ms * 1e-3) / 1e12
+        traffic, traffic_src = measured_traffic("tower_tile_kernel<32, true") if world == 1 else (None, None)
         res = {
-            "metric": "scored user-item pairs/sec (NeuMF fwd, whole node)", "value": pairs / elapsed, "unit": "pairs/s",
+            "metric": "scored user-item pairs/sec (NeuMF fwd, whole node); full-catalog top-100 users/s",
+            "value": pairs / elapsed, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "users_per_s_top%d" % K: N_USERS * world * args.steps / elapsed,
             "config": {"workload": "cfg2: NeuMF (factor 32, 3 MLP layers) full-catalog scoring + top-10, ML-1M NCF id space "
-                                   "6038 users x 3533 items = 21,332,254 pairs per GPU per step",
+                                   "6038 users x 3533 items = 21,332,254 pairs per GPU per step (`value`); cfg5 (10M x 1M, top-100) in "
+                                   "`cfg5_top100`, same ranks, same protocol",
                        "users_per_gpu": N_USERS, "items": N_ITEMS, "k": K, "weights": "random init, reference ctor order, seed 0, embeddings x25",
-                       "parallelism": "user-sharded x%d, replicated tables, RCCL all-gather of top-k (%s)" % (
-                           world, "overlapped with the next step's kernels" if gather_mode["pipelined"] else "blocking: the overlapped form failed")},
-            "roofline": {"bound": "mfma", "kernel": "tower_tile_kernel<32,true>", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": measured_traffic("tower_tile_kernel<32, true") if world == 1 else None,
-                         "traffic_note": "HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/*_hbm_traffic.json), not live; "
-                                         "algorithmic output is 85.3 MB per launch",
-                         "kernel_ms": tile_ms, "launches_timed": n_timed, "flop_per_pair_algorithmic": FLOP_PER_PAIR,
-                         "executed": {"flop_per_pair": FLOP_PER_PAIR_EXEC, "achieved": executed, "frac": executed / PEAK_F32_MFMA_TFLOPS,
-                                      "note": "layer 1 is factorised (W1[u;i] = W1u u + W1i i): frac above counts the reference's "
-                                              "86,176 FLOP/pair, this one the FLOPs the kernel issues; MFMA utilisation is the executed figure"}},
+                       "parallelism": "user-sharded x%d, replicated tables, %s all-gather of top-k (%s)" % (
+                           world, "gloo (REHEARSAL: ranks share GPUs, numbers meaningless)" if args.share_gpus else "RCCL",
+                           "overlapped with the next step's kernels" if pipelined else
+                           ("blocking; the overlapped form failed and the ranks were restarted" if os.environ.get("RECO_BENCH_FELL_BACK") == "1"
+                            else "blocking (RECO_BENCH_SYNC_GATHER=1)"))},
+            "roofline": mfma_roofline("tower_tile_kernel<32,true>", pairs_per_rank, tile_ms, n_timed, traffic, traffic_src,
+                                      algorithmic_bytes=pairs_per_rank * 4),
         }
-        dev = (s_vals - vals).abs() / vals.abs().clamp_min(1e-30)
-        res["split_bf16x3"] = {
-            "value": pairs / s_elapsed, "unit": "pairs/s", "ms_per_step": s_elapsed / args.steps * 1e3,
-            "kernel": "tower_tile_split_kernel<32,true>", "kernel_ms": s_tile_ms, "speedup_vs_f32": elapsed / s_elapsed,
-            "top%d_ids_equal_to_f32" % K: float((s_ids == ids).double().mean().item()),
-            "top%d_scores_max_rel_dev_vs_f32" % K: float(dev.max().item()),
-            "note": "opt-in RECO_PREC_SPLIT_BF16X3 (not the headline): fp32 operands split exactly into three bf16 pieces, six cross "
-                    "terms on v_mfma_f32_32x32x16_bf16, fp32 accumulate; passes the same parity tests as the exact mode"}
+        if split is not None:
+            s_elapsed, s_tile_ms, _, s_ids, s_vals = split
+            dev = (s_vals - vals).abs() / vals.abs().clamp_min(1e-30)
+            res["split_bf16x3"] = {
+                "value": pairs / s_elapsed, "unit": "pairs/s", "ms_per_step": s_elapsed / args.steps * 1e3,
+                "kernel": "tower_tile_split_kernel<32,true>", "kernel_ms": s_tile_ms, "speedup_vs_f32": elapsed / s_elapsed,
+                "top%d_ids_equal_to_f32" % K: float((s_ids == ids).double().mean().item()),
+                "top%d_scores_max_rel_dev_vs_f32" % K: float(dev.max().item()),
+                "note": "opt-in RECO_PREC_SPLIT_BF16X3 (not the headline): fp32 operands split exactly into three bf16 pieces, six cross "
+                        "terms on v_mfma_f32_32x32x16_bf16, fp32 accumulate; passes the same parity tests as the exact mode"}
         if cfg5 is not None:
             res["cfg5_top100"] = cfg5
         if world == 1 and not args.no_cpu_baseline:
@@ -251,7 +365,16 @@ def main():
     if launched:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return self_launch(args, argv)
+    return main_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -18,6 +18,12 @@
  *     unless the comment says "synchronises";
  *   - return 0 on success, a negative RECO_E* code otherwise; reco_last_error() gives the
  *     thread-local message;
+ *   - ids out of range never fault and never assert on the device: they are clamped to the nearest
+ *     valid row and counted in the call's `oob` argument (device int32, nullable = do not count; the caller zeroes it
+ *     and reads it back when it wants nn.Embedding's IndexError, src/api/core/inference_engine.py:17-31).  The counter
+ *     belongs to the call, not to a handle: concurrent callers never see each other's ids;
+ *   - NaN conventions: ReLU is max on the raw bits (one VALU instruction beside the MFMAs): a NaN with the sign bit set
+ *     becomes +0 where torch.relu would propagate it; NaN inputs are outside the parity contract;
  *   - nothing allocates except *_create (the packed-model handles) -- scratch memory is
  *     brought in by the caller as `ws` / `ws_bytes` (query the size with *_workspace_bytes).
  */
@@ -146,9 +152,9 @@ int  reco_tower_create(const reco_tower_desc_t* desc, void* stream, reco_tower_t
 void reco_tower_destroy(reco_tower_t* t);
 
 /* forward(user, item) -> score[B]           src/helpers/ncf_model.py:188-249
- * Out-of-range ids never fault: they are clamped and counted; reco_tower_status() reports them. */
+ * Out-of-range ids never fault: they are clamped and counted in *oob (see Conventions). */
 int reco_tower_score_pairs(reco_tower_t* t, const int64_t* user, const int64_t* item, int64_t B,
-                           float* out, void* stream);
+                           float* out, int32_t* oob, void* stream);
 
 /* Score B pairs whose embedding rows are handed over directly (row b of each matrix belongs to
  * pair b) -- the Hybrid forward, where every pair brings its own encoder latents
@@ -160,9 +166,6 @@ int reco_tower_score_rows(reco_tower_t* t, const float* u_gmf, const float* i_gm
                           const float* u_mlp, const float* i_mlp, int64_t B, float* out,
                           void* ws, size_t ws_bytes, void* stream);
 
-/* Number of out-of-range ids seen since the last call (and resets it).  Synchronises `stream`. */
-int64_t reco_tower_status(reco_tower_t* t, void* stream);
-
 /* Full (user x candidate) score matrix: out[u, n] = score(users[u], cands[n])
  * replaces the per-user loop around model(user_t, item_t)  src/api/core/inference_engine.py:149-164
  * users NULL -> user_base + u;  cands NULL -> n.  out row stride ld_out (floats).
@@ -170,7 +173,7 @@ int64_t reco_tower_status(reco_tower_t* t, void* stream);
 size_t reco_tower_matrix_workspace_bytes(int64_t U, int64_t N);
 int reco_tower_score_matrix(reco_tower_t* t, const int64_t* users, int64_t user_base, int64_t U,
                             const int64_t* cands, int64_t N, float* out, int64_t ld_out,
-                            void* ws, size_t ws_bytes, void* stream);
+                            int32_t* oob, void* ws, size_t ws_bytes, void* stream);
 
 /* score_matrix + per-user top-k (K-d), user-chunked so the score rows live only in `ws`.
  * replaces model(...) + np.argsort(scores)[::-1][:k]       inference_engine.py:162-166
@@ -183,7 +186,7 @@ size_t reco_tower_topk_workspace_bytes(int64_t U, int64_t N, int k);
 int reco_tower_score_topk(reco_tower_t* t, const int64_t* users, int64_t user_base, int64_t U,
                           const int64_t* cands, int64_t N, int k,
                           const uint8_t* exclude, int64_t ld_ex,
-                          int32_t* out_ids, float* out_scores,
+                          int32_t* out_ids, float* out_scores, int32_t* oob,
                           void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("RECO_HIP_LIB") or os.path.join(_HERE, "lib", "libreco
 OK, EINVAL, EHIP, ENOMEM, EINDEX = 0, -1, -2, -3, -4
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_CLAMP, ACT_RATING = 0, 1, 2, 3, 4
 PREC_F32, PREC_SPLIT_BF16X3 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class TowerDesc(Structure):
@@ -45,17 +45,16 @@ _SIGNATURES = {
                                      c_int, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "reco_tower_create": (c_int, [POINTER(TowerDesc), c_void_p, POINTER(c_void_p)]),
     "reco_tower_destroy": (None, [c_void_p]),
-    "reco_tower_score_pairs": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "reco_tower_score_pairs": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "reco_tower_rows_workspace_bytes": (c_size_t, [c_int64]),
     "reco_tower_score_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                       c_void_p, c_size_t, c_void_p]),
-    "reco_tower_status": (c_int64, [c_void_p, c_void_p]),
     "reco_tower_matrix_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "reco_tower_score_matrix": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64,
-                                        c_void_p, c_size_t, c_void_p]),
+                                        c_void_p, c_void_p, c_size_t, c_void_p]),
     "reco_tower_topk_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "reco_tower_score_topk": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int,
-                                      c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                      c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "reco_topk_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "reco_topk_rows": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p,
                                c_void_p, c_size_t, c_void_p]),

@@ -54,7 +54,7 @@ void reco_set_error(const char* fmt, ...)
 }
 
 extern "C" const char* reco_last_error(void) { return g_err; }
-extern "C" int reco_abi_version(void) { return 2; }
+extern "C" int reco_abi_version(void) { return 3; }
 
 // ---------------------------------------------------------------------------------------------
 // measurement hook: hipEvent pairs around the dominant kernel's launches
@@ -179,23 +179,22 @@ struct reco_tower {
     void* img_split;  // bf16x3 image (RECO_PREC_SPLIT_BF16X3 only)
     float* P;         // [n_users,128] layer-1 user projection (+ b1)
     float* Q;         // [n_items,128] layer-1 item projection
-    int32_t* oob;     // device counter of clamped ids
     int device;
 };
 
 static int tower_project(const reco_tower* t, const float* u_rows, const int64_t* u_idx, int64_t u_limit, int64_t U,
                          const float* i_rows, const int64_t* i_idx, int64_t i_limit, int64_t N,
-                         float* P, float* Q, hipStream_t s)
+                         float* P, float* Q, int32_t* oob, hipStream_t s)
 {
     const int dm = t->d.dm;
     if (U > 0) {
         int rc = launch_linear_f32(u_rows, dm, u_idx, u_limit, U, t->d.W[0], 2 * dm, t->d.b[0], H1, dm, RECO_ACT_NONE,
-                                   0.f, 0.f, P, H1, t->oob, nullptr, 0, s);
+                                   0.f, 0.f, P, H1, oob, nullptr, 0, s);
         if (rc) return rc;
     }
     if (N > 0) {
         int rc = launch_linear_f32(i_rows, dm, i_idx, i_limit, N, t->d.W[0] + dm, 2 * dm, nullptr, H1, dm,
-                                   RECO_ACT_NONE, 0.f, 0.f, Q, H1, t->oob, nullptr, 0, s);
+                                   RECO_ACT_NONE, 0.f, 0.f, Q, H1, oob, nullptr, 0, s);
         if (rc) return rc;
     }
     return RECO_OK;
@@ -229,7 +228,6 @@ extern "C" void reco_tower_destroy(reco_tower_t* t)
     (void)hipFree(t->img_split);
     (void)hipFree(t->P);
     (void)hipFree(t->Q);
-    (void)hipFree(t->oob);
     delete t;
 }
 
@@ -278,9 +276,8 @@ extern "C" int reco_tower_create(const reco_tower_desc_t* d, void* stream, reco_
     }
 
     int rc = RECO_OK;
-    hipError_t e = hipMalloc(&t->oob, 256);
-    if (e == hipSuccess) e = hipMemsetAsync(t->oob, 0, 256, s);
-    if (e == hipSuccess && t->mfma) e = hipMalloc(&t->img, IMG_SIZE * sizeof(float));
+    hipError_t e = hipSuccess;
+    if (t->mfma) e = hipMalloc(&t->img, IMG_SIZE * sizeof(float));
     const bool split = t->mfma && d->precision == RECO_PREC_SPLIT_BF16X3;
     if (e == hipSuccess && split) e = hipMalloc(&t->img_split, tower_split_image_bytes(t->has_l3));
     if (e == hipSuccess && t->mfma && tables) e = hipMalloc(&t->P, (size_t)d->n_users * H1 * sizeof(float));
@@ -297,7 +294,7 @@ extern "C" int reco_tower_create(const reco_tower_desc_t* d, void* stream, reco_
         if (!rc && split)
             rc = tower_pack_split_image(d->W[1], t->has_l3 ? d->W[2] : nullptr, t->has_l3, t->img, t->img_split, s);
         if (!rc && tables)
-            rc = tower_project(t, d->user_mlp, nullptr, 0, d->n_users, d->item_mlp, nullptr, 0, d->n_items, t->P, t->Q, s);
+            rc = tower_project(t, d->user_mlp, nullptr, 0, d->n_users, d->item_mlp, nullptr, 0, d->n_items, t->P, t->Q, nullptr, s);
     }
     if (!rc) {
         e = hipStreamSynchronize(s);
@@ -308,19 +305,8 @@ extern "C" int reco_tower_create(const reco_tower_desc_t* d, void* stream, reco_
     return RECO_OK;
 }
 
-extern "C" int64_t reco_tower_status(reco_tower_t* t, void* stream)
-{
-    if (!t) return 0;
-    int32_t n = 0;
-    hipStream_t s = (hipStream_t)stream;
-    if (hipMemcpyAsync(&n, t->oob, sizeof(n), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
-    if (hipStreamSynchronize(s) != hipSuccess) return -1;
-    if (n != 0 && hipMemsetAsync(t->oob, 0, sizeof(int32_t), s) != hipSuccess) return -1;
-    return n;
-}
-
 extern "C" int reco_tower_score_pairs(reco_tower_t* t, const int64_t* user, const int64_t* item, int64_t B,
-                                      float* out, void* stream)
+                                      float* out, int32_t* oob, void* stream)
 {
     RECO_REQUIRE(t, "score_pairs: null handle");
     if (int rc_dev = check_device(t, "score_pairs")) return rc_dev;
@@ -331,9 +317,9 @@ extern "C" int reco_tower_score_pairs(reco_tower_t* t, const int64_t* user, cons
     const reco_tower_desc_t& d = t->d;
     if (!t->mfma)
         return gmf_launch_pairs(d.user_gmf, d.item_gmf, d.w_predict, user, item, d.n_users, d.n_items, B, d.dg, out,
-                                t->bp, d.act, d.lo, d.hi, t->oob, s);
+                                t->bp, d.act, d.lo, d.hi, oob, s);
     ProfScope prof(s);
-    return run_pairs(t, t->P, t->Q, d.user_gmf, d.item_gmf, user, item, d.n_users, d.n_items, B, out, t->oob, s);
+    return run_pairs(t, t->P, t->Q, d.user_gmf, d.item_gmf, user, item, d.n_users, d.n_items, B, out, oob, s);
 }
 
 extern "C" size_t reco_tower_rows_workspace_bytes(int64_t B)
@@ -362,7 +348,7 @@ extern "C" int reco_tower_score_rows(reco_tower_t* t, const float* u_gmf, const 
     if (!ws || ws_bytes < 2 * half) { reco_set_error("score_rows: workspace too small (%zu < %zu)", ws_bytes, 2 * half); return RECO_ENOMEM; }
     float* P = static_cast<float*>(ws);
     float* Q = reinterpret_cast<float*>(static_cast<char*>(ws) + half);
-    int rc = tower_project(t, u_mlp, nullptr, 0, B, i_mlp, nullptr, 0, B, P, Q, s);
+    int rc = tower_project(t, u_mlp, nullptr, 0, B, i_mlp, nullptr, 0, B, P, Q, nullptr, s);
     if (rc) return rc;
     ProfScope prof(s);
     return run_pairs(t, P, Q, u_gmf, i_gmf, nullptr, nullptr, B, B, B, out, nullptr, s);
@@ -376,24 +362,24 @@ extern "C" size_t reco_tower_matrix_workspace_bytes(int64_t U, int64_t N) { retu
 
 static int score_matrix_impl(reco_tower* t, const int64_t* users, int64_t user_base, int64_t U,
                              const int64_t* cands, int64_t N, const float* Qready, float* out, int64_t ld_out,
-                             float* P, float* Q, unsigned int* queue, hipStream_t s)
+                             float* P, float* Q, unsigned int* queue, int32_t* oob, hipStream_t s)
 {
     const reco_tower_desc_t& d = t->d;
     if (!t->mfma)
         return gmf_launch_tile(d.user_gmf, d.item_gmf, d.w_predict, users, cands, user_base, d.n_users, d.n_items, U, N,
-                               d.dg, out, ld_out, t->bp, d.act, d.lo, d.hi, t->oob, s);
+                               d.dg, out, ld_out, t->bp, d.act, d.lo, d.hi, oob, s);
     // layer-1 projections for exactly these users / candidates, inside the call
     const float* urows = users ? d.user_mlp : d.user_mlp + user_base * d.dm;
-    int rc = tower_project(t, urows, users, d.n_users, U, d.item_mlp, cands, d.n_items, Qready ? 0 : N, P, Q, s);
+    int rc = tower_project(t, urows, users, d.n_users, U, d.item_mlp, cands, d.n_items, Qready ? 0 : N, P, Q, oob, s);
     if (rc) return rc;
     if (queue) RECO_CHECK_HIP(hipMemsetAsync(queue, 0, sizeof(unsigned int), s));
     ProfScope prof(s);
     if (t->img_split)
         return tower_launch_tile_split(t->G, t->has_l3, t->img_split, P, Qready ? Qready : Q, d.user_gmf, d.item_gmf, users,
                                        cands, user_base, d.n_users, d.n_items, U, N, out, ld_out, t->bp, d.act, d.lo, d.hi,
-                                       t->oob, queue, s);
+                                       oob, queue, s);
     return tower_launch_tile(t->G, t->has_l3, t->img, P, Qready ? Qready : Q, d.user_gmf, d.item_gmf, users, cands,
-                             user_base, d.n_users, d.n_items, U, N, out, ld_out, t->bp, d.act, d.lo, d.hi, t->oob, queue, s);
+                             user_base, d.n_users, d.n_items, U, N, out, ld_out, t->bp, d.act, d.lo, d.hi, oob, queue, s);
 }
 
 static int check_ranges(const reco_tower* t, const int64_t* users, int64_t user_base, int64_t U, const int64_t* cands,
@@ -409,7 +395,7 @@ static int check_ranges(const reco_tower* t, const int64_t* users, int64_t user_
 
 extern "C" int reco_tower_score_matrix(reco_tower_t* t, const int64_t* users, int64_t user_base, int64_t U,
                                        const int64_t* cands, int64_t N, float* out, int64_t ld_out,
-                                       void* ws, size_t ws_bytes, void* stream)
+                                       int32_t* oob, void* ws, size_t ws_bytes, void* stream)
 {
     RECO_REQUIRE(t, "score_matrix: null handle");
     if (int rc_dev = check_device(t, "score_matrix")) return rc_dev;
@@ -426,7 +412,7 @@ extern "C" int reco_tower_score_matrix(reco_tower_t* t, const int64_t* users, in
         P = reinterpret_cast<float*>(static_cast<char*>(ws) + kQueueBytes);
         Q = reinterpret_cast<float*>(static_cast<char*>(ws) + kQueueBytes + proj_bytes(U));
     }
-    return score_matrix_impl(t, users, user_base, U, cands, N, nullptr, out, ld_out, P, Q, queue, (hipStream_t)stream);
+    return score_matrix_impl(t, users, user_base, U, cands, N, nullptr, out, ld_out, P, Q, queue, oob, (hipStream_t)stream);
 }
 
 // user-chunk size for the fused score + top-k path
@@ -458,28 +444,23 @@ extern "C" size_t reco_tower_topk_workspace_bytes(int64_t U, int64_t N, int k)
     return topk_chunk_bytes(default_chunk(U, N), N, k);
 }
 
-extern "C" int reco_tower_score_topk(reco_tower_t* t, const int64_t* users, int64_t user_base, int64_t U,
-                                     const int64_t* cands, int64_t N, int k,
-                                     const uint8_t* exclude, int64_t ld_ex,
-                                     int32_t* out_ids, float* out_scores,
-                                     void* ws, size_t ws_bytes, void* stream)
+static int score_topk_impl(reco_tower_t* t, const int64_t* users, int64_t user_base, int64_t U,
+                           const int64_t* cands, int64_t N, int k, const uint8_t* exclude, int64_t ld_ex,
+                           int32_t* out_ids, float* out_scores, int32_t* oob, void* ws, size_t ws_bytes, hipStream_t s,
+                           const char* who)
 {
-    RECO_REQUIRE(t, "score_topk: null handle");
-    if (int rc_dev = check_device(t, "score_topk")) return rc_dev;
-    if (U <= 0) return RECO_OK;
-    RECO_REQUIRE(out_ids && out_scores, "score_topk: null output");
-    RECO_REQUIRE(k >= 1 && k <= 128, "score_topk: k must be in [1,128], got %d", k);
-    RECO_REQUIRE(N >= k, "score_topk: k=%d exceeds the number of candidates %lld", k, (long long)N);
-    RECO_REQUIRE(!exclude || ld_ex >= N, "score_topk: ld_ex smaller than N");
-    int rc = check_ranges(t, users, user_base, U, cands, N, "score_topk");
+    RECO_REQUIRE(out_ids && out_scores, "%s: null output", who);
+    RECO_REQUIRE(k >= 1 && k <= 128, "%s: k must be in [1,128], got %d", who, k);
+    RECO_REQUIRE(N >= k, "%s: k=%d exceeds the number of candidates %lld", who, k, (long long)N);
+    RECO_REQUIRE(!exclude || ld_ex >= N, "%s: ld_ex smaller than N", who);
+    int rc = check_ranges(t, users, user_base, U, cands, N, who);
     if (rc) return rc;
-    hipStream_t s = (hipStream_t)stream;
 
     // largest user chunk the workspace admits
     int64_t Uc = default_chunk(U, N);
     while (Uc > 1 && topk_chunk_bytes(Uc, N, k) > ws_bytes) Uc = Uc / 2;
     if (!ws || topk_chunk_bytes(Uc, N, k) > ws_bytes) {
-        reco_set_error("score_topk: workspace too small (%zu bytes; one user needs %zu)", ws_bytes, topk_chunk_bytes(1, N, k));
+        reco_set_error("%s: workspace too small (%zu bytes; one user needs %zu)", who, ws_bytes, topk_chunk_bytes(1, N, k));
         return RECO_ENOMEM;
     }
     char* w = static_cast<char*>(ws);
@@ -497,16 +478,29 @@ extern "C" int reco_tower_score_topk(reco_tower_t* t, const int64_t* users, int6
     const bool cached_q = t->mfma && !cands && N == d.n_items && U <= kServingUsers && t->Q;
     if (cached_q) Q = t->Q;
     else if (t->mfma) {
-        rc = tower_project(t, nullptr, nullptr, 0, 0, d.item_mlp, cands, d.n_items, N, nullptr, Q, s);
+        rc = tower_project(t, nullptr, nullptr, 0, 0, d.item_mlp, cands, d.n_items, N, nullptr, Q, oob, s);
         if (rc) return rc;
     }
     for (int64_t c0 = 0; c0 < U; c0 += Uc) {
         const int64_t n = U - c0 < Uc ? U - c0 : Uc;
-        rc = score_matrix_impl(t, users ? users + c0 : nullptr, user_base + c0, n, cands, N, Q, scores, ldN, P, Q, queue, s);
+        rc = score_matrix_impl(t, users ? users + c0 : nullptr, user_base + c0, n, cands, N, Q, scores, ldN, P, Q, queue, oob, s);
         if (rc) return rc;
         rc = launch_topk_rows(scores, n, N, ldN, k, exclude ? exclude + c0 * ld_ex : nullptr, ld_ex, out_ids + c0 * k,
                               out_scores + c0 * k, tws, tws_bytes, s);
         if (rc) return rc;
     }
     return RECO_OK;
+}
+
+extern "C" int reco_tower_score_topk(reco_tower_t* t, const int64_t* users, int64_t user_base, int64_t U,
+                                     const int64_t* cands, int64_t N, int k,
+                                     const uint8_t* exclude, int64_t ld_ex,
+                                     int32_t* out_ids, float* out_scores, int32_t* oob,
+                                     void* ws, size_t ws_bytes, void* stream)
+{
+    RECO_REQUIRE(t, "score_topk: null handle");
+    if (int rc_dev = check_device(t, "score_topk")) return rc_dev;
+    if (U <= 0) return RECO_OK;
+    return score_topk_impl(t, users, user_base, U, cands, N, k, exclude, ld_ex, out_ids, out_scores, oob, ws, ws_bytes,
+                           (hipStream_t)stream, "score_topk");
 }

@@ -7,9 +7,55 @@ in one packed int32 buffer).  With user sharding the lists are disjoint, so the 
 
 `TopkGather` keeps that collective off the critical path: the gather of step i runs on RCCL's stream while the scoring
 kernels of step i + 1 run on the compute stream (two packed buffers in flight).
+
+Ordering of the collective behind the kernels that produce its input ("the round-1 hang"):
+RCCL ("nccl") launches the collective as a kernel on its own stream behind an event recorded on the caller's stream, so
+it is stream-ordered by construction.  Any other backend (gloo: the CPU tests, and rehearsals where several ranks share
+one GPU) stages device tensors through host memory from a helper thread; issued asynchronously behind unfinished
+kernels, that staging never completed on a shared GPU (both ranks stuck in work.wait() for good).  For those backends
+the producer is therefore finished first (an event recorded behind the top-k kernel, waited for on the host) and
+work.wait() carries a timeout, so a stuck collective raises GatherTimeout instead of hanging the job.
 """
+import datetime
+import os
+
 import torch
 import torch.distributed as dist
+
+
+class GatherTimeout(RuntimeError):
+    """The top-k all-gather did not complete in time.  The process group is not usable afterwards: callers restart the
+    job (bench.py relaunches its ranks with the blocking gather), they do not retry in-process."""
+
+
+def gather_timeout_s():
+    return float(os.environ.get("RECO_GATHER_TIMEOUT_S", "60"))
+
+
+def _stream_ordered(group=None):
+    """True when the backend enqueues collectives on the device behind the caller's stream (RCCL)."""
+    return dist.is_initialized() and str(dist.get_backend(group)).lower() == "nccl"
+
+
+def _finish_producer(t):
+    """Host-waits for everything enqueued so far on the current stream of t's device (no-op for host tensors)."""
+    if t.is_cuda:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(t.device))
+        ev.synchronize()
+
+
+def _wait(work, stream_ordered):
+    """Makes the collective's result visible to the caller's stream / thread; raises GatherTimeout instead of hanging."""
+    if stream_ordered:
+        work.wait()          # the compute stream waits for RCCL's stream, the host does not; a stuck collective is ended
+        return               # by the process group's own watchdog (timeout set at init_process_group)
+    try:
+        done = work.wait(datetime.timedelta(seconds=gather_timeout_s()))
+    except RuntimeError as exc:
+        raise GatherTimeout("top-k all-gather did not complete within %.0f s: %s" % (gather_timeout_s(), exc)) from exc
+    if done is False:
+        raise GatherTimeout("top-k all-gather did not complete within %.0f s" % gather_timeout_s())
 
 
 def shard_range(total, rank, world):
@@ -69,7 +115,10 @@ def all_gather_topk(ids, vals, counts=None, group=None):
     mx = max(counts)
     buf = _pack(ids, vals, mx)
     out = torch.empty((world * 2, mx, k), dtype=torch.int32, device=ids.device)    # concatenation along dim 0
-    dist.all_gather_into_tensor(out, buf, group=group)
+    ordered = _stream_ordered(group)
+    if not ordered:
+        _finish_producer(buf)
+    _wait(dist.all_gather_into_tensor(out, buf, group=group, async_op=True), ordered)
     return _unpack(out.view(world, 2, mx, k), counts, k)
 
 
@@ -101,13 +150,17 @@ class TopkGather:
 
     step() enqueues this rank's scoring + top-k into one of two packed buffers and starts the all-gather of that buffer
     asynchronously; the gather overlaps the next step's kernels.  Results are (ids [U,k], scores [U,k]) in user order.
-    A result may alias a pipeline buffer: it stays valid until two further step() calls.
+    A result aliases a pipeline buffer and stays valid only until the NEXT step() call, which scores (and gathers) into
+    that same buffer: copy what must live longer.
     Without an initialised process group it degenerates to the local call.
+    A gather that does not complete raises GatherTimeout (non-RCCL backends) or is ended by the process group's
+    watchdog (RCCL): see the module docstring.
     """
 
     def __init__(self, model, k, total_users=None, candidates=None, group=None):
         self.k, self.candidates, self.group = k, candidates, group
         self.on = dist.is_initialized()
+        self.ordered = _stream_ordered(group)
         self.rank = dist.get_rank(group) if self.on else 0
         self.world = dist.get_world_size(group) if self.on else 1
         self.device = model._compute_device()
@@ -131,8 +184,8 @@ class TopkGather:
     def _collect(self, slot):
         if not self.on:
             return slot["ids"], slot["vals"]
-        slot["work"].wait()                     # the compute stream waits for the collective; the host does not
-        slot["work"] = None
+        work, slot["work"] = slot["work"], None
+        _wait(work, self.ordered)
         return _unpack(slot["gathered"].view(self.world, 2, -1, self.k), self.counts, self.k)
 
     def step(self):
@@ -141,6 +194,8 @@ class TopkGather:
         self.tower.score_topk((self.start, self.count), self.k, self.candidates, None, check_ids=False, ws=self.ws,
                               out=(slot["ids"], slot["vals"]))
         if self.on:
+            if not self.ordered:
+                _finish_producer(slot["buf"])
             slot["work"] = dist.all_gather_into_tensor(slot["gathered"], slot["buf"], group=self.group, async_op=True)
         done = self._collect(self.pending) if self.pending is not None else None
         self.pending = slot

@@ -317,11 +317,13 @@ class Tower:
             self._L.reco_tower_destroy(h)
             self._h = None
 
-    def _raise_if_oob(self):
-        n = self._L.reco_tower_status(self._h, _stream(self.device))
-        if n < 0:
-            raise RuntimeError("reco_hip: reco_tower_status failed")
-        if n:
+    def _oob(self, check_ids):
+        """Per-call counter of clamped ids (None: the caller validated its ids, nothing is counted and nothing synchronises)."""
+        return torch.zeros(1, dtype=torch.int32, device=self.device) if check_ids else None
+
+    @staticmethod
+    def _raise_if_oob(oob):
+        if oob is not None and int(oob.item()):
             raise IndexError("index out of range in self")
 
     def score_pairs(self, user, item, check_ids=True):
@@ -329,10 +331,10 @@ class Tower:
         if user.numel() != item.numel():
             raise ValueError("user and item must have the same length (%d vs %d)" % (user.numel(), item.numel()))
         out = torch.empty(user.numel(), dtype=torch.float32, device=self.device)
+        oob = self._oob(check_ids)
         with torch.cuda.device(self.device):
-            check(self._L.reco_tower_score_pairs(self._h, _p(user), _p(item), user.numel(), _p(out), _stream(self.device)))
-            if check_ids:
-                self._raise_if_oob()
+            check(self._L.reco_tower_score_pairs(self._h, _p(user), _p(item), user.numel(), _p(out), _p(oob), _stream(self.device)))
+            self._raise_if_oob(oob)
         return out
 
     def score_rows(self, u_gmf, i_gmf, u_mlp, i_mlp):
@@ -371,11 +373,11 @@ class Tower:
             _check_out(out, (U, N), torch.float32, self.device, "out", rows_may_be_strided=True)
         nbytes = self._L.reco_tower_matrix_workspace_bytes(U, N)
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.device)
+        oob = self._oob(check_ids)
         with torch.cuda.device(self.device):
             check(self._L.reco_tower_score_matrix(self._h, _p(uptr), base, U, _p(cands), N, _p(out), out.stride(0),
-                                                  _p(ws), nbytes, _stream(self.device)))
-            if check_ids:
-                self._raise_if_oob()
+                                                  _p(oob), _p(ws), nbytes, _stream(self.device)))
+            self._raise_if_oob(oob)
         return out
 
     def topk_workspace(self, U, N, k):
@@ -403,11 +405,11 @@ class Tower:
             ws = self.topk_workspace(U, N, k)
         elif not (isinstance(ws, torch.Tensor) and ws.dtype == torch.uint8 and ws.device == self.device and ws.is_contiguous()):
             raise ValueError("ws must be the uint8 tensor topk_workspace() returned, on %s" % self.device)
+        oob = self._oob(check_ids)
         with torch.cuda.device(self.device):
             check(self._L.reco_tower_score_topk(self._h, _p(uptr), base, U, _p(cands), N, k, _p(exclude), N, _p(ids),
-                                                _p(vals), _p(ws), ws.numel(), _stream(self.device)))
-            if check_ids:
-                self._raise_if_oob()
+                                                _p(vals), _p(oob), _p(ws), ws.numel(), _stream(self.device)))
+            self._raise_if_oob(oob)
         return ids, vals
 
 

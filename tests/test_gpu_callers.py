@@ -152,9 +152,9 @@ def test_c_abi_rejects_bad_arguments_with_error_codes_not_faults():
     torch.manual_seed(0)
     t = NCF(40, 30, 32, 3, 0.0, "NeuMF-end").eval().cuda()._tower(dev)
     out = torch.empty(40, 30, device=dev)
-    refused(L.reco_tower_score_matrix(t._h, None, 0, 40, None, 30, p(out), 30, None, 0, st), _lib.ENOMEM, "workspace")
-    refused(L.reco_tower_score_matrix(t._h, None, 35, 10, None, 30, p(out), 30, None, 0, st), _lib.EINVAL, "user range")
-    refused(L.reco_tower_score_pairs(None, None, None, 4, None, st), _lib.EINVAL, "null handle")
+    refused(L.reco_tower_score_matrix(t._h, None, 0, 40, None, 30, p(out), 30, None, None, 0, st), _lib.ENOMEM, "workspace")
+    refused(L.reco_tower_score_matrix(t._h, None, 35, 10, None, 30, p(out), 30, None, None, 0, st), _lib.EINVAL, "user range")
+    refused(L.reco_tower_score_pairs(None, None, None, 4, None, None, st), _lib.EINVAL, "null handle")
     with pytest.raises(ValueError):
         ops.Tower(w_predict=torch.zeros(64, device=dev), b_predict=torch.zeros(1, device=dev), precision="fp8")
     torch.cuda.synchronize()

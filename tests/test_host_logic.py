@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), "libreco_hip.so does not export %s" % name
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert L.reco_abi_version() == _lib.ABI_VERSION == 2
+    assert L.reco_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_tower_desc_layout_matches_header():
@@ -38,7 +38,7 @@ def test_c_abi_argument_errors_without_gpu():
     assert L.reco_topk_rows(None, 4, 10, 10, 0, None, 0, None, None, None, 0, None) == _lib.EINVAL
     assert b"k must be" in L.reco_last_error() or b"null" in L.reco_last_error()
     assert L.reco_gather_rows(None, 10, 30, None, 5, None, None, None) == _lib.EINVAL
-    assert L.reco_tower_score_pairs(None, None, None, 3, None, None) == _lib.EINVAL
+    assert L.reco_tower_score_pairs(None, None, None, 3, None, None, None) == _lib.EINVAL
     assert L.reco_tower_topk_workspace_bytes(6038, 3533, 10) > 6038 * 3533 * 4
     with pytest.raises(ValueError):
         _lib.check(_lib.EINVAL)

@@ -9,6 +9,7 @@ contiguous slice of `users_per_gpu` users against the whole catalog per step and
 The full job (10 M users) is this step repeated 10 M / (N x users_per_gpu) times; the extrapolated time is printed as such.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -18,7 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.distributed as dist
 
-from recommender_amd import ops
+from recommender_amd import _lib, ops
 from recommender_amd.dist import all_gather_topk
 
 U_TOTAL, N_ITEMS, K = 10_000_000, 1_000_000, 100
@@ -61,12 +62,20 @@ def _run(dev, world, rank, launched, upg, steps, warmup, precision):
 
     for i in range(warmup):
         step(i)
+    L = _lib.lib()
+    cap = steps * (upg // 32 + 2) + 4                 # one tile-kernel launch per user chunk (256 users at 1 M items)
+    _lib.check(L.reco_profile_enable(cap))
     fence()
     t0 = time.perf_counter()
     for i in range(steps):
         step(warmup + i)
     fence()
     el = time.perf_counter() - t0
+    ms = (ctypes.c_float * cap)()
+    n = ctypes.c_int(0)
+    _lib.check(L.reco_profile_collect(ms, cap, ctypes.byref(n)))
+    _lib.check(L.reco_profile_enable(0))
+    tile_ms_total = float(sum(list(ms)[: n.value]))    # all tile-kernel launches of this rank's timed steps
     t = torch.tensor([el], dtype=torch.float64, device=dev)
     if launched:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -77,11 +86,27 @@ def _run(dev, world, rank, launched, upg, steps, warmup, precision):
     if rank != 0:
         return None
     users = upg * world * steps
+    # executed FLOPs of the tile kernel (layer 1 factorised) over the fp32 MFMA peak: hardware utilisation
+    flop_exec, flop_alg, peak = 20768, 86176, 157.3
+    pairs_rank = upg * steps * N_ITEMS
+    tile_s = tile_ms_total * 1e-3
+    roofline = None
+    if n.value and tile_s > 0:
+        roofline = {"bound": "mfma", "kernel": "tower_tile%s_kernel<32,true>" % ("_split" if precision == "bf16x3" else ""),
+                    "achieved": pairs_rank * flop_exec / tile_s / 1e12, "peak": peak, "unit": "TFLOP/s",
+                    "frac": pairs_rank * flop_exec / tile_s / 1e12 / peak, "flop_per_pair_executed": flop_exec,
+                    "kernel_ms": tile_ms_total / n.value, "launches_timed": n.value, "pairs_per_launch": pairs_rank // n.value,
+                    "kernel_share_of_step": tile_s / el,
+                    "algorithmic": {"flop_per_pair": flop_alg, "ratio_to_peak": pairs_rank * flop_alg / tile_s / 1e12 / peak,
+                                    "note": "reference FLOP count over the fp32 MFMA peak; not a hardware fraction"},
+                    "traffic": None}
+        if precision == "bf16x3":
+            roofline["note"] = "fp32-equivalent FLOPs over the FP32 MFMA peak (the kernel multiplies on the bf16 MFMA)"
     return {"metric": "full-catalog top-100 users/s (synthetic NeuMF 10M users x 1M items)", "value": users / el, "unit": "users/s",
             "pairs_per_s": users * N_ITEMS / el, "n_gpus": world, "steps": steps, "ms_per_step": el / steps * 1e3,
             "users_per_gpu_per_step": upg, "scaling": "weak", "dtype": "f32", "precision": precision,
             "data": "synthetic (on-device N(0,0.01)x25 tables, seed 5)",
-            "full_job_extrapolated_s": U_TOTAL / (users / el), "hbm_resident_GB": resident}
+            "full_job_extrapolated_s": U_TOTAL / (users / el), "hbm_resident_GB": resident, "roofline": roofline}
 
 
 def main():
