@@ -189,6 +189,22 @@ int reco_tower_score_topk(reco_tower_t* t, const int64_t* users, int64_t user_ba
                           int32_t* out_ids, float* out_scores, int32_t* oob,
                           void* ws, size_t ws_bytes, void* stream);
 
+/* The same call for callers that cannot allocate or bring a workspace (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Identical results to
+ * reco_tower_score_topk; the call workspace is a static device array of RECO_NOALLOC_SCRATCH_BYTES inside the library
+ * (one copy per GPU, held until the process ends).  Calls no hipMalloc / hipFree / allocating routine.
+ * Limits: the candidates of ONE user chunk must fit, i.e. reco_tower_topk_workspace_bytes(1, N, k) <=
+ * RECO_NOALLOC_SCRATCH_BYTES (about 48,000 candidates at k = 128, 63,000 at k = 10) -- beyond that the call returns
+ * RECO_EINVAL and launches nothing; any number of users (they are chunked to fit).
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two threads) RACE; serialise
+ * them or use reco_tower_score_topk with separate workspaces. */
+#define RECO_NOALLOC_SCRATCH_BYTES (32u << 20)
+size_t reco_noalloc_scratch_bytes(void);
+int reco_tower_score_topk_noalloc(reco_tower_t* t, const int64_t* users, int64_t user_base, int64_t U,
+                                  const int64_t* cands, int64_t N, int k,
+                                  const uint8_t* exclude, int64_t ld_ex,
+                                  int32_t* out_ids, float* out_scores, int32_t* oob, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * K-d  per-row top-k select (wavefront-level)
  * replaces np.argsort(...)[::-1][:k] (inference_engine.py:166), torch.topk (ncf.ipynb cell 8),

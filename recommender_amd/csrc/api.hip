@@ -231,6 +231,8 @@ extern "C" void reco_tower_destroy(reco_tower_t* t)
     delete t;
 }
 
+static int scratch_lookup(int device);   // no-alloc entry point's static scratch (end of this file)
+
 extern "C" int reco_tower_create(const reco_tower_desc_t* d, void* stream, reco_tower_t** out)
 {
     RECO_REQUIRE(d && out, "tower_create: null argument");
@@ -252,6 +254,7 @@ extern "C" int reco_tower_create(const reco_tower_desc_t* d, void* stream, reco_
     hipStream_t s = (hipStream_t)stream;
     int device = -1;
     RECO_CHECK_HIP(hipGetDevice(&device));
+    if (int rc_s = scratch_lookup(device)) return rc_s;
     reco_tower* t = new (std::nothrow) reco_tower();
     if (!t) { reco_set_error("tower_create: out of host memory"); return RECO_ENOMEM; }
     t->d = *d;
@@ -503,4 +506,57 @@ extern "C" int reco_tower_score_topk(reco_tower_t* t, const int64_t* users, int6
     if (U <= 0) return RECO_OK;
     return score_topk_impl(t, users, user_base, U, cands, N, k, exclude, ld_ex, out_ids, out_scores, oob, ws, ws_bytes,
                            (hipStream_t)stream, "score_topk");
+}
+
+// ---------------------------------------------------------------------------------------------
+// score_topk for callers that cannot allocate (HIP graph capture, tight serving loops): the call workspace is a
+// file-scope device array instead of a caller buffer.  Every GPU the library runs on holds its own copy of the array
+// (at its own address) until the process ends.  The array's NAME is a host-side stand-in, not a device address: host
+// code only ever uses the per-device pointer that hipGetSymbolAddress returned, looked up once per device in
+// reco_tower_create (the library's allocating set-up call) with that device current.
+// ---------------------------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char scratch[RECO_NOALLOC_SCRATCH_BYTES];
+static void* g_scratch_ptr[RECO_MAX_DEVICES] = {};      // device -> address of that device's copy of `scratch`
+static std::mutex g_scratch_mu;
+
+// called from reco_tower_create with the handle's device current
+static int scratch_lookup(int device)
+{
+    RECO_REQUIRE(device >= 0 && device < RECO_MAX_DEVICES, "device index %d out of range", device);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[device]) return RECO_OK;
+    void* ptr = nullptr;
+    RECO_CHECK_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    RECO_REQUIRE(ptr != nullptr, "hipGetSymbolAddress returned a null address for the static scratch array");
+    g_scratch_ptr[device] = ptr;
+    return RECO_OK;
+}
+
+extern "C" size_t reco_noalloc_scratch_bytes(void) { return RECO_NOALLOC_SCRATCH_BYTES; }
+
+extern "C" int reco_tower_score_topk_noalloc(reco_tower_t* t, const int64_t* users, int64_t user_base, int64_t U,
+                                             const int64_t* cands, int64_t N, int k,
+                                             const uint8_t* exclude, int64_t ld_ex,
+                                             int32_t* out_ids, float* out_scores, int32_t* oob, void* stream)
+{
+    RECO_REQUIRE(t, "score_topk_noalloc: null handle");
+    if (int rc_dev = check_device(t, "score_topk_noalloc")) return rc_dev;
+    if (U <= 0) return RECO_OK;
+    RECO_REQUIRE(N > 0 && k >= 1 && k <= 128, "score_topk_noalloc: need N > 0 and k in [1,128], got N=%lld k=%d", (long long)N, k);
+    const size_t one_user = topk_chunk_bytes(1, N, k);
+    RECO_REQUIRE(one_user <= (size_t)RECO_NOALLOC_SCRATCH_BYTES,
+                 "score_topk_noalloc: N=%lld candidates at k=%d need %zu bytes of scratch per user chunk, the static scratch "
+                 "holds %zu; use reco_tower_score_topk with a caller workspace", (long long)N, k, one_user,
+                 (size_t)RECO_NOALLOC_SCRATCH_BYTES);
+    void* ptr = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        ptr = g_scratch_ptr[t->device];
+    }
+    RECO_REQUIRE(ptr != nullptr, "score_topk_noalloc: no scratch address recorded for device %d", t->device);
+    // the array keeps the previous call's bytes: the only word that must start at zero is the tile queue counter, which
+    // score_matrix_impl clears (hipMemsetAsync on `stream`) before every tile-kernel launch; every other region is
+    // written before it is read within the call
+    return score_topk_impl(t, users, user_base, U, cands, N, k, exclude, ld_ex, out_ids, out_scores, oob, ptr,
+                           (size_t)RECO_NOALLOC_SCRATCH_BYTES, (hipStream_t)stream, "score_topk_noalloc");
 }
