@@ -189,6 +189,20 @@ int reco_tower_score_topk(reco_tower_t* t, const int64_t* users, int64_t user_ba
                           int32_t* out_ids, float* out_scores, int32_t* oob,
                           void* ws, size_t ws_bytes, void* stream);
 
+/* score_matrix / score_topk over row blocks handed in per call: out[u, n] = score(row u of the user blocks, row n of the item
+ * blocks) for all U x N combinations -- the Hybrid model's full-catalog evaluation, where the "tables" are this call's encoder
+ * latents (replaces the O(blocks x items) full-model loop of hybridautorecncf.ipynb cell 13 around
+ * evaluate_hybridautorecncf_rating.py:197-208).  u_gmf/i_gmf [U|N, dg], u_mlp/i_mlp [U|N, dm]; the handle may have been created
+ * without tables.  Workspace sizes: reco_tower_matrix_workspace_bytes(U, N) / reco_tower_topk_workspace_bytes(U, N, k).
+ * Nothing is allocated, nothing synchronises; top-k ids are row numbers of the item blocks. */
+int reco_tower_score_matrix_rows(reco_tower_t* t, const float* u_gmf, const float* i_gmf,
+                                 const float* u_mlp, const float* i_mlp, int64_t U, int64_t N,
+                                 float* out, int64_t ld_out, void* ws, size_t ws_bytes, void* stream);
+int reco_tower_score_topk_rows(reco_tower_t* t, const float* u_gmf, const float* i_gmf,
+                               const float* u_mlp, const float* i_mlp, int64_t U, int64_t N, int k,
+                               const uint8_t* exclude, int64_t ld_ex, int32_t* out_ids, float* out_scores,
+                               void* ws, size_t ws_bytes, void* stream);
+
 /* The same call for callers that cannot allocate or bring a workspace (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Identical results to
  * reco_tower_score_topk; the call workspace is a static device array of RECO_NOALLOC_SCRATCH_BYTES inside the library
@@ -215,6 +229,16 @@ size_t reco_topk_workspace_bytes(int64_t rows, int64_t N, int k);
 int reco_topk_rows(const float* scores, int64_t rows, int64_t N, int64_t ld, int k,
                    const uint8_t* exclude, int64_t ld_ex,
                    int32_t* out_ids, float* out_vals, void* ws, size_t ws_bytes, void* stream);
+
+/* The AutoRec / Hybrid ranking evaluation's form of the same select (src/autorec/utils/helper.py:272,313,335):
+ *   train_mask = train_mat > 0;  predictions = predictions*(~train_mask) - train_mask*1e10;  argsort(...)[-k:][::-1]
+ * `seen` (nullable) is the float rating matrix itself, [src_rows, N] with row stride ld_seen: an entry > 0 marks the item as
+ * seen -- no mask tensor is built.  row_ids (nullable, int64 [rows]) selects the users: output row r is the top-k of source
+ * row row_ids[r] (ids outside [0, src_rows) are clamped and counted in *oob); NULL = every source row in order (rows ignored).
+ * Workspace: reco_topk_workspace_bytes(number of output rows, N, k). */
+int reco_topk_rows_seen(const float* scores, int64_t src_rows, int64_t N, int64_t ld, int k,
+                        const int64_t* row_ids, int64_t rows, const float* seen, int64_t ld_seen,
+                        int32_t* out_ids, float* out_vals, int32_t* oob, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement hook (no counterpart in the reference): when enabled, the library brackets every

@@ -55,12 +55,18 @@ _SIGNATURES = {
     "reco_tower_topk_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "reco_tower_score_topk": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int,
                                       c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "reco_tower_score_matrix_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64,
+                                             c_void_p, c_size_t, c_void_p]),
+    "reco_tower_score_topk_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
+                                           c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "reco_noalloc_scratch_bytes": (c_size_t, []),
     "reco_tower_score_topk_noalloc": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int,
                                               c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "reco_topk_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "reco_topk_rows": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p,
                                c_void_p, c_size_t, c_void_p]),
+    "reco_topk_rows_seen": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int64,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "reco_profile_enable": (c_int, [c_int]),
     "reco_profile_collect": (c_int, [POINTER(c_float), c_int, POINTER(c_int)]),
 }

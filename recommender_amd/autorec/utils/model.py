@@ -91,14 +91,11 @@ class AutoRec(nn.Module):
         Returns (item ids int32 [U,k], scores [U,k]); order: descending score, ascending item id on ties.
         """
         device = self._device_of(train_matrix)
-        m = train_matrix.to(device=device, dtype=torch.float32)
+        m = train_matrix.to(device=device, dtype=torch.float32).contiguous()
         pred = self.reconstruct_all(m, clamp)
-        seen = (m > 0) if mask_seen else None
-        if users is not None:
-            users = torch.as_tensor(users, dtype=torch.int64, device=device)
-            pred = pred.index_select(0, users)
-            seen = seen.index_select(0, users) if seen is not None else None
-        return ops.topk_rows(pred, k, seen)
+        # the seen mask (train > 0, helper.py:272) is read off the rating matrix inside the select and the user subset is an
+        # index list handed to the kernel: no mask tensor, no gathered copies
+        return ops.topk_rows_seen(pred, k, m if mask_seen else None, users)
 
     # -- N1: cached hidden layer for serving ------------------------------------------------------------------
     def cache_hidden(self, train_matrix):

@@ -166,6 +166,16 @@ extern "C" int reco_topk_rows(const float* scores, int64_t rows, int64_t N, int6
     return launch_topk_rows(scores, rows, N, ld, k, exclude, ld_ex, out_ids, out_vals, ws, ws_bytes, (hipStream_t)stream);
 }
 
+extern "C" int reco_topk_rows_seen(const float* scores, int64_t src_rows, int64_t N, int64_t ld, int k,
+                                   const int64_t* row_ids, int64_t rows, const float* seen, int64_t ld_seen,
+                                   int32_t* out_ids, float* out_vals, int32_t* oob, void* ws, size_t ws_bytes, void* stream)
+{
+    RECO_REQUIRE(ld >= N, "topk_rows_seen: ld smaller than N");
+    RECO_REQUIRE(src_rows >= 0 && rows >= 0, "topk_rows_seen: negative row count");
+    return launch_topk_rows_ex(scores, row_ids ? rows : src_rows, N, ld, k, nullptr, 0, seen, ld_seen, row_ids, src_rows, oob,
+                               out_ids, out_vals, ws, ws_bytes, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------------------------------------
 // tower handle
 // ---------------------------------------------------------------------------------------------
@@ -506,6 +516,47 @@ extern "C" int reco_tower_score_topk(reco_tower_t* t, const int64_t* users, int6
     if (U <= 0) return RECO_OK;
     return score_topk_impl(t, users, user_base, U, cands, N, k, exclude, ld_ex, out_ids, out_scores, oob, ws, ws_bytes,
                            (hipStream_t)stream, "score_topk");
+}
+
+// ---- matrix / top-k forms over row blocks handed in per call (the Hybrid head: tables = this call's encoder latents) ----
+// A shallow copy of the handle with the caller's row blocks in place of the tables runs the same code path: the projections
+// are recomputed per call inside the workspace anyway, nothing is allocated and nothing synchronises.
+static int rows_view(const reco_tower_t* t, const float* u_gmf, const float* i_gmf, const float* u_mlp, const float* i_mlp,
+                     int64_t U, int64_t N, reco_tower* v, const char* who)
+{
+    RECO_REQUIRE(t, "%s: null handle", who);
+    if (int rc_dev = check_device(t, who)) return rc_dev;
+    RECO_REQUIRE(U >= 0 && N >= 0 && U < (1ll << 31) && N < (1ll << 31), "%s: bad row counts", who);
+    if (t->d.dg > 0) RECO_REQUIRE(u_gmf && i_gmf, "%s: GMF rows missing", who);
+    if (t->d.dm > 0) RECO_REQUIRE(u_mlp && i_mlp, "%s: MLP rows missing", who);
+    RECO_REQUIRE((uintptr_t)u_gmf % 16 == 0 && (uintptr_t)i_gmf % 16 == 0 && (uintptr_t)u_mlp % 16 == 0 && (uintptr_t)i_mlp % 16 == 0,
+                 "%s: row blocks must be 16-byte aligned (rows are read as float4)", who);
+    *v = *t;
+    v->d.user_gmf = u_gmf; v->d.item_gmf = i_gmf; v->d.user_mlp = u_mlp; v->d.item_mlp = i_mlp;
+    v->d.n_users = U; v->d.n_items = N;
+    v->P = nullptr; v->Q = nullptr;        // the handle's cached projections belong to its own tables
+    return RECO_OK;
+}
+
+extern "C" int reco_tower_score_matrix_rows(reco_tower_t* t, const float* u_gmf, const float* i_gmf,
+                                            const float* u_mlp, const float* i_mlp, int64_t U, int64_t N,
+                                            float* out, int64_t ld_out, void* ws, size_t ws_bytes, void* stream)
+{
+    reco_tower v;
+    if (int rc = rows_view(t, u_gmf, i_gmf, u_mlp, i_mlp, U, N, &v, "score_matrix_rows")) return rc;
+    if (U <= 0 || N <= 0) return RECO_OK;
+    return reco_tower_score_matrix(&v, nullptr, 0, U, nullptr, N, out, ld_out, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int reco_tower_score_topk_rows(reco_tower_t* t, const float* u_gmf, const float* i_gmf,
+                                          const float* u_mlp, const float* i_mlp, int64_t U, int64_t N, int k,
+                                          const uint8_t* exclude, int64_t ld_ex, int32_t* out_ids, float* out_scores,
+                                          void* ws, size_t ws_bytes, void* stream)
+{
+    reco_tower v;
+    if (int rc = rows_view(t, u_gmf, i_gmf, u_mlp, i_mlp, U, N, &v, "score_topk_rows")) return rc;
+    if (U <= 0) return RECO_OK;
+    return reco_tower_score_topk(&v, nullptr, 0, U, nullptr, N, k, exclude, ld_ex, out_ids, out_scores, nullptr, ws, ws_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -74,4 +74,8 @@ size_t linear_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int launch_topk_rows(const float* scores, int64_t rows, int64_t N, int64_t ld, int k,
                      const uint8_t* exclude, int64_t ld_ex, int32_t* out_ids, float* out_vals,
                      void* ws, size_t ws_bytes, hipStream_t s);
+int launch_topk_rows_ex(const float* scores, int64_t rows, int64_t N, int64_t ld, int k,
+                        const uint8_t* exclude, int64_t ld_ex, const float* seen, int64_t ld_seen,
+                        const int64_t* row_ids, int64_t src_rows, int32_t* oob, int32_t* out_ids, float* out_vals,
+                        void* ws, size_t ws_bytes, hipStream_t s);
 size_t topk_workspace_bytes(int64_t rows, int64_t N, int k);

@@ -17,6 +17,10 @@
 // waves; a second launch merges the per-segment lists the same way.
 #include "reco_common.h"
 
+#ifndef RECO_TOPK_UN
+#define RECO_TOPK_UN 4       // float4 loads in flight per lane: 4 KB per wave, 16 MB over the chip at 4 waves per SIMD
+#endif
+
 namespace {
 
 typedef unsigned long long u64;
@@ -205,6 +209,11 @@ struct TopkArgs {
     int k;
     const uint8_t* exclude;
     int64_t ld_ex;
+    const float* seen;      // nullable: float matrix whose entries > 0 mark seen items (train_mask = train_mat > 0, helper.py:272)
+    int64_t ld_seen;
+    const int64_t* row_ids; // nullable: output row r selects row row_ids[r] of scores / exclude / seen
+    int64_t src_rows;       // rows of the source matrices when row_ids is given (ids are clamped into [0, src_rows))
+    int32_t* oob;           // nullable: count of clamped row ids
     int splits;
     int64_t seg;            // elements per split (multiple of 64)
     u64* partial;           // [rows][splits][k] when splits > 1
@@ -224,16 +233,28 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(TopkArgs a)
     const int split = (int)(w % a.splits);
     const int64_t s0 = split * a.seg;
     const int64_t s1 = s0 + a.seg < a.N ? s0 + a.seg : a.N;
-    const float* src = a.scores + row * a.ld;
-    const uint8_t* ex = a.exclude ? a.exclude + row * a.ld_ex : nullptr;
+    int64_t srow = row;
+    if (a.row_ids) {
+        srow = a.row_ids[row];
+        if (srow < 0 || srow >= a.src_rows) {
+            if (a.oob && lane == 0 && split == 0) atomicAdd(a.oob, 1);
+            srow = srow < 0 ? 0 : a.src_rows - 1;
+        }
+    }
+    const float* src = a.scores + srow * a.ld;
+    const uint8_t* ex = a.exclude ? a.exclude + srow * a.ld_ex : nullptr;
+    const float* sf = a.seen ? a.seen + srow * a.ld_seen : nullptr;
+    const bool masked = ex != nullptr || sf != nullptr;
 
     WaveList<SLOTS> L;
     L.clear();
     Pending P;
     P.clear();
     u64 thr = 0;
+    // (Measured and dropped in round 2: a float pre-filter "score >= k-th score" in front of the key build, per 256-element block
+    // 0.354 -> 0.383 ms and per 64-element offer 0.354 -> 0.353 ms on 256 x 1M, k = 100: the key build is not what bounds the scan.)
     if constexpr (VEC == 4) {
-        constexpr int UN = 2;
+        constexpr int UN = RECO_TOPK_UN;
         auto load = [&](int64_t base, f32x4* v) {
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
@@ -258,7 +279,7 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(TopkArgs a)
                     const int64_t n = base + u * 256 + 4 * lane + t;
                     const bool ok = n < s1;
                     float x = v[u][t];
-                    if (ex && ok && ex[n]) x = x * 0.f - 1e10f;   // helper.py:313: pred*(~seen) - seen*1e10
+                    if (masked && ok && ((ex && ex[n]) || (sf && sf[n] > 0.f))) x = x * 0.f - 1e10f;   // helper.py:313
                     const u64 key = ((u64)float_key(x) << 32) | (uint32_t)~(uint32_t)n;
                     offer<SLOTS>(L, P, key, ok, thr, a.k, lane);
                 }
@@ -274,7 +295,7 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(TopkArgs a)
                 const int64_t n = base + t * 64 + lane;
                 ok[t] = n < s1;
                 v[t] = ok[t] ? src[n] : 0.f;
-                if (ex && ok[t] && ex[n]) v[t] = v[t] * 0.f - 1e10f;   // helper.py:313: pred*(~seen) - seen*1e10
+                if (masked && ok[t] && ((ex && ex[n]) || (sf && sf[n] > 0.f))) v[t] = v[t] * 0.f - 1e10f;   // helper.py:313
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -457,13 +478,24 @@ int launch_topk_rows(const float* scores, int64_t rows, int64_t N, int64_t ld, i
                      const uint8_t* exclude, int64_t ld_ex, int32_t* out_ids, float* out_vals,
                      void* ws, size_t ws_bytes, hipStream_t s)
 {
+    return launch_topk_rows_ex(scores, rows, N, ld, k, exclude, ld_ex, nullptr, 0, nullptr, rows, nullptr, out_ids, out_vals,
+                               ws, ws_bytes, s);
+}
+
+int launch_topk_rows_ex(const float* scores, int64_t rows, int64_t N, int64_t ld, int k,
+                        const uint8_t* exclude, int64_t ld_ex, const float* seen, int64_t ld_seen,
+                        const int64_t* row_ids, int64_t src_rows, int32_t* oob, int32_t* out_ids, float* out_vals,
+                        void* ws, size_t ws_bytes, hipStream_t s)
+{
     if (rows <= 0) return RECO_OK;
     RECO_REQUIRE(k >= 1 && k <= 128, "topk: k must be in [1,128], got %d", k);
     RECO_REQUIRE(N >= k, "topk: k=%d exceeds the number of candidates %lld", k, (long long)N);
     RECO_REQUIRE(N < (1ll << 32) - 1, "topk: row too long");
     RECO_REQUIRE(scores && out_ids && out_vals, "topk: null pointer");
-    TopkArgs a{scores, rows, N, ld, k, exclude, ld_ex, 1, 0, nullptr, out_ids, out_vals};
-    if (!exclude && k <= 16 && N <= 512 && rows >= 32768) {        // many short rows: a lane per row (topk_lane_kernel)
+    RECO_REQUIRE(!seen || ld_seen >= N, "topk: ld_seen smaller than N");
+    RECO_REQUIRE(!row_ids || src_rows > 0, "topk: row ids given but the source has no rows");
+    TopkArgs a{scores, rows, N, ld, k, exclude, ld_ex, seen, ld_seen, row_ids, src_rows, oob, 1, 0, nullptr, out_ids, out_vals};
+    if (!exclude && !seen && !row_ids && k <= 16 && N <= 512 && rows >= 32768) {        // many short rows: a lane per row (topk_lane_kernel)
         const int64_t lblocks = ceil_div64(rows, 256);
         RECO_REQUIRE(lblocks < (1ll << 31), "topk grid too large");
         const bool v4 = ld % 4 == 0 && (uintptr_t)scores % 16 == 0;

@@ -18,6 +18,7 @@ import torch.nn as nn
 from .. import ops
 
 _tower_cache = weakref.WeakKeyDictionary()
+_weight_cache = weakref.WeakKeyDictionary()      # AutoEncoder -> {id(Sequential): (signature, [(weight, bias) on device])}
 
 
 def _f32_on(t, device):
@@ -48,13 +49,24 @@ class AutoEncoder(nn.Module):
                 nn.init.xavier_uniform_(m.weight)
                 nn.init.zeros_(m.bias)
 
-    @staticmethod
-    def _run(seq, x, final_act, transposed=False):
+    def _device_weights(self, seq, device):
+        """[(weight, bias)] of seq's Linear layers as fp32 tensors on `device`; copies (CPU-resident or non-fp32 parameters)
+        are made once and kept until a parameter's version counter changes."""
         linears = [m for m in seq if isinstance(m, nn.Linear)]
-        for n, lin in enumerate(linears):
-            last = n + 1 == len(linears)
-            x = ops.linear(x, _f32_on(lin.weight, x.device), _f32_on(lin.bias, x.device),
-                           act=(final_act if last else "relu"), x_transposed=(transposed and n == 0))
+        ps = [p for lin in linears for p in (lin.weight, lin.bias)]
+        sig = (str(device),) + tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
+        cache = _weight_cache.setdefault(self, {})
+        hit = cache.get(id(seq))
+        if hit is None or hit[0] != sig:
+            hit = (sig, [(_f32_on(lin.weight, device), _f32_on(lin.bias, device)) for lin in linears])
+            cache[id(seq)] = hit
+        return hit[1]
+
+    def _run(self, seq, x, final_act, transposed=False):
+        weights = self._device_weights(seq, x.device)
+        for n, (w, b) in enumerate(weights):
+            last = n + 1 == len(weights)
+            x = ops.linear(x, w, b, act=(final_act if last else "relu"), x_transposed=(transposed and n == 0))
         return x
 
     def _prep(self, x):
@@ -128,17 +140,17 @@ class NCF(nn.Module):
         out = self._tower(device).score_rows(zu, zi, zu, zi)
         return out if out.device == src else out.to(src)
 
-    def score_matrix(self, zu, zi):
-        """pred[u, i] for every (row of zu, row of zi): the full-catalog form of forward."""
+    def score_matrix(self, zu, zi, k=None, exclude=None):
+        """pred[u, i] for every (row of zu, row of zi) -- the full-catalog form of forward -- or, with k, the per-user top-k
+        (ids = row numbers of zi).  Runs on the cached head (weights packed once, keyed on parameter versions); the latents are
+        handed to the kernels per call, so nothing is allocated besides the outputs and nothing synchronises."""
         ops.require_gpu()
         device = zu.device if zu.is_cuda else torch.device("cuda", torch.cuda.current_device())
         zu = _f32_on(zu, device); zi = _f32_on(zi, device)
-        linears = [m for m in self.mlp if isinstance(m, nn.Linear)]
-        tower = ops.Tower(user_gmf=zu, item_gmf=zi, user_mlp=zu, item_mlp=zi,
-                          layers=[(_f32_on(l.weight, device), _f32_on(l.bias, device)) for l in linears],
-                          w_predict=_f32_on(self.output.weight, device), b_predict=_f32_on(self.output.bias, device),
-                          act="rating" if self.rating_output else None, lo=float(self.rating_min), hi=float(self.rating_max))
-        return tower
+        tower = self._tower(device)
+        if k is None:
+            return tower.score_matrix_rows(zu, zi, zu, zi)
+        return tower.score_topk_rows(zu, zi, zu, zi, k, exclude)
 
 
 class HybridAutoRecNCF(nn.Module):
@@ -163,7 +175,4 @@ class HybridAutoRecNCF(nn.Module):
         R = rating_matrix.to(device=device, dtype=torch.float32).contiguous()
         zu = self.user_autorec.encode(R)
         zi = self.item_autorec.encode(R, transposed=True)
-        tower = self.ncf.score_matrix(zu, zi)
-        if k is None:
-            return tower.score_matrix(None, None, check_ids=False)
-        return tower.score_topk(None, k, None, exclude, check_ids=False)
+        return self.ncf.score_matrix(zu, zi, k, exclude)

@@ -193,6 +193,45 @@ def topk_rows(scores, k, exclude=None):
     return ids, vals
 
 
+def topk_rows_seen(scores, k, seen=None, rows=None, check_ids=True):
+    """Per-user top-k of a score matrix with the ranking evaluation's seen-item mask taken straight from the float rating
+    matrix (helper.py:272,313: seen = train_mat > 0; score*(~seen) - seen*1e10) and an optional user selection.
+
+    scores [U, N] (row-strided views are read in place); seen: float32 [U, N] rating matrix or None; rows: int64 user ids or
+    None (all users in order).  Returns (ids int32 [R,k], vals [R,k]); no mask tensor and no gathered copies are built.
+    """
+    if not (isinstance(scores, torch.Tensor) and scores.dim() == 2 and scores.is_cuda and scores.dtype == torch.float32
+            and scores.stride(1) == 1 and scores.stride(0) >= scores.shape[1]):
+        scores = _f32(scores, "scores", 2)
+    U, N = scores.shape
+    ld = scores.stride(0) if U > 1 else N
+    ld_seen = 0
+    if seen is not None:
+        if not (isinstance(seen, torch.Tensor) and seen.dim() == 2 and seen.is_cuda and seen.dtype == torch.float32
+                and seen.stride(1) == 1 and seen.stride(0) >= seen.shape[1]):
+            seen = _f32(seen, "seen", 2)
+        if tuple(seen.shape) != (U, N) or seen.device != scores.device:
+            raise ValueError("seen must be a float32 [%d, %d] matrix on %s, got %s" % (U, N, scores.device, tuple(seen.shape)))
+        ld_seen = seen.stride(0) if U > 1 else N
+    if rows is not None:
+        rows = _i64(rows, "rows", scores.device)
+    R = U if rows is None else rows.numel()
+    ids = torch.empty((R, k), dtype=torch.int32, device=scores.device)
+    vals = torch.empty((R, k), dtype=torch.float32, device=scores.device)
+    if R == 0:                  # an empty selection (its data pointer is NULL, which the C ABI reads as "all rows")
+        return ids, vals
+    L = _lib.lib()
+    nbytes = L.reco_topk_workspace_bytes(R, N, k)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=scores.device)
+    oob = torch.zeros(1, dtype=torch.int32, device=scores.device) if (check_ids and rows is not None) else None
+    with torch.cuda.device(scores.device):
+        check(L.reco_topk_rows_seen(_p(scores), U, N, ld, k, _p(rows), R, _p(seen), ld_seen, _p(ids), _p(vals), _p(oob),
+                                    _p(ws), nbytes, _stream(scores.device)))
+    if oob is not None and int(oob.item()):
+        raise IndexError("index out of range in self")
+    return ids, vals
+
+
 def _check_out(t, shape, dtype, device, name, rows_may_be_strided=False):
     """A caller-provided output tensor is handed to the kernels as a raw pointer: its extents must be what they assume."""
     ok = isinstance(t, torch.Tensor) and tuple(t.shape) == tuple(shape) and t.dtype == dtype and t.device == device
@@ -352,6 +391,47 @@ class Tower:
             check(self._L.reco_tower_score_rows(self._h, _p(tens[0]), _p(tens[1]), _p(tens[2]), _p(tens[3]), B, _p(out),
                                                 _p(ws), nbytes, _stream(self.device)))
         return out
+
+    def _row_blocks(self, u_gmf, i_gmf, u_mlp, i_mlp):
+        U = (u_mlp if u_mlp is not None else u_gmf).shape[0]
+        N = (i_mlp if i_mlp is not None else i_gmf).shape[0]
+        tens = [None if t is None else _f32(t, "rows", 2) for t in (u_gmf, i_gmf, u_mlp, i_mlp)]
+        for name, t, rows, width in (("u_gmf", tens[0], U, self.dg), ("i_gmf", tens[1], N, self.dg),
+                                     ("u_mlp", tens[2], U, self.dm), ("i_mlp", tens[3], N, self.dm)):
+            if width and (t is None or tuple(t.shape) != (rows, width) or t.device != self.device):
+                raise ValueError("%s must be a [%d, %d] float32 tensor on %s, got %s"
+                                 % (name, rows, width, self.device, None if t is None else tuple(t.shape)))
+        return tens, U, N
+
+    def score_matrix_rows(self, u_gmf, i_gmf, u_mlp, i_mlp, out=None):
+        """scores[u, n] for every (row u of the user blocks, row n of the item blocks): score_matrix with per-call tables."""
+        tens, U, N = self._row_blocks(u_gmf, i_gmf, u_mlp, i_mlp)
+        if out is None:
+            out = torch.empty((U, N), dtype=torch.float32, device=self.device)
+        else:
+            _check_out(out, (U, N), torch.float32, self.device, "out", rows_may_be_strided=True)
+        nbytes = self._L.reco_tower_matrix_workspace_bytes(U, N)
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self._L.reco_tower_score_matrix_rows(self._h, _p(tens[0]), _p(tens[1]), _p(tens[2]), _p(tens[3]), U, N, _p(out),
+                                                       out.stride(0) if U > 1 else N, _p(ws), nbytes, _stream(self.device)))
+        return out
+
+    def score_topk_rows(self, u_gmf, i_gmf, u_mlp, i_mlp, k=10, exclude=None, ws=None):
+        """(ids int32 [U,k] = row numbers of the item blocks, scores [U,k]): score_topk with per-call tables."""
+        tens, U, N = self._row_blocks(u_gmf, i_gmf, u_mlp, i_mlp)
+        if exclude is not None:
+            exclude = _mask(exclude, tens[2] if tens[2] is not None else tens[0])
+            if tuple(exclude.shape) != (U, N):
+                raise ValueError("exclude mask must have shape (%d, %d), got %s" % (U, N, tuple(exclude.shape)))
+        ids = torch.empty((U, k), dtype=torch.int32, device=self.device)
+        vals = torch.empty((U, k), dtype=torch.float32, device=self.device)
+        if ws is None:
+            ws = self.topk_workspace(U, N, k)
+        with torch.cuda.device(self.device):
+            check(self._L.reco_tower_score_topk_rows(self._h, _p(tens[0]), _p(tens[1]), _p(tens[2]), _p(tens[3]), U, N, k,
+                                                     _p(exclude), N, _p(ids), _p(vals), _p(ws), ws.numel(), _stream(self.device)))
+        return ids, vals
 
     def _users(self, users):
         """users: None (all), int range tuple (base, count), or id tensor."""

@@ -83,12 +83,28 @@ def test_cfg1_full_protocol_size_pair_list(tower_precision):
     ids, _ = ops.topk_rows(s.view(cases, 100), 10)
     top_items = np.take_along_axis(items, ids.cpu().numpy().astype(np.int64), 1)
     hr, nd = hit_ndcg_batch(top_items, items[:, 0])
-    # oracle HR/NDCG on a slice of cases computed from oracle scores
-    sl = slice(0, 4096)
-    osc = O.ncf_forward(sd, np.repeat(users[sl], 100), items[sl].reshape(-1)).reshape(-1, 100)
-    oid, _ = O.topk_rows(osc, 10)
-    ohr, ond = O.protocol_metrics(np.take_along_axis(items[sl], oid.astype(np.int64), 1), items[sl, 0])
-    assert abs(hr[sl].mean() - ohr.mean()) <= 1.0 / 4096 and abs(nd[sl].mean() - ond.mean()) <= 1e-3
+    # north_star: "HR@10/NDCG@10 identical on the 99-negative protocol" -- per case, over ALL 115,056 cases, against the
+    # reference's own ATen ops on the host (oracle/torch_ref.py), evaluated the reference's way (ncf.ipynb cell 8: topk, take,
+    # hit / ndcg).  A case may differ only if the reference's own scores tie within the parity tolerance somewhere in its top 11
+    # (then the order of those two candidates is not defined by the reference either).
+    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+    osc = torch.cat([T.ncf_forward(sdt, u.cpu()[a:a + (1 << 20)], it.cpu()[a:a + (1 << 20)]) for a in range(0, cases * 100, 1 << 20)])
+    osc = osc.view(cases, 100).numpy()
+    assert_close(s.cpu().numpy().reshape(cases, 100), osc, what="cfg1 all 11.5 M pairs vs the reference's ATen ops")
+    oid, oval = O.topk_rows(osc, 11)
+    ohr, ond = hit_ndcg_batch(np.take_along_axis(items, oid[:, :10].astype(np.int64), 1), items[:, 0])
+    chk = rng.choice(cases, 2048, replace=False)                       # the batched metric equals the reference's scalar loops
+    shr, snd = O.protocol_metrics(np.take_along_axis(items[chk], oid[chk, :10].astype(np.int64), 1), items[chk, 0])
+    assert np.array_equal(shr, ohr[chk]) and np.array_equal(snd, ond[chk])
+    differ = np.where((hr != ohr) | (nd != ond))[0]
+    gaps = np.abs(np.diff(oval[differ], axis=1))
+    tol = 1e-5 * np.abs(oval[differ, :-1]) + 1e-6
+    assert ((gaps <= tol).any(axis=1)).all(), "HR/NDCG differ on cases whose reference scores do not tie"
+    assert len(differ) <= cases // 1000, "%d cases excused by near-ties" % len(differ)
+    print("cfg1 full protocol: HR@10 %.6f NDCG@10 %.6f (reference ops: %.6f / %.6f); %d of %d cases excused by near-ties" % (
+        hr.mean(), nd.mean(), ohr.mean(), ond.mean(), len(differ), cases))
+    if len(differ) == 0:
+        assert hr.mean() == ohr.mean() and nd.mean() == ond.mean()
 
 
 def test_cfg3_autorec_full_reconstruction_and_masked_topk(tower_precision):
@@ -192,3 +208,67 @@ def test_split_mode_deviation_is_at_fp32_rounding_level():
     print("max |score| %.3f; max abs deviation from fp64: exact fp32 MFMA %.3e, split bf16x3 %.3e" % (scale, err["f32"], err["bf16x3"]))
     assert err["f32"] <= 1e-6 * max(scale, 1.0)
     assert err["bf16x3"] <= 2.0 * err["f32"] + 1e-7 * max(scale, 1.0)
+
+
+_cfg5_ref = {}
+
+
+def test_cfg5_full_size_tables_row_offsets_beyond_4_gib(tower_precision):
+    """BASELINE configs[4] at its real table sizes: 10 M x {32, 128} user tables (1.28 + 5.12 GB, byte offsets of rows cross
+    2^31 and 2^32), 1 M items, top-100.  Users spread over [0, 1e7) are scored by the tile path (id list and id range) and the
+    pair path, and compared with the reference's ATen ops fed only those users' rows (the tables never leave the GPU)."""
+    from recommender_amd import ops
+    from recommender_amd.helpers import NCF
+    dev = torch.device("cuda", 0)
+    U, I, K = 10_000_000, 1_000_000, 100
+    g = torch.Generator(device=dev).manual_seed(5)
+
+    def table(rows, dim):
+        return torch.randn(rows, dim, device=dev, generator=g) * 0.25
+
+    ug, ig, um, im = table(U, 32), table(I, 32), table(U, 128), table(I, 128)
+    torch.manual_seed(0)
+    small = NCF(8, 8, 32, 3, 0.0, "NeuMF-end").eval()
+    gen = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        for n, p in small.named_parameters():
+            if n.endswith("bias"):
+                p.copy_(torch.empty_like(p).uniform_(-0.2, 0.2, generator=gen))
+    layers = [(l.weight.detach().to(dev), l.bias.detach().to(dev)) for l in small.MLP_layers if isinstance(l, torch.nn.Linear)]
+    tower = ops.Tower(user_gmf=ug, item_gmf=ig, user_mlp=um, item_mlp=im, layers=layers,
+                      w_predict=small.predict_layer.weight.detach().to(dev), b_predict=small.predict_layer.bias.detach().to(dev))
+    # 2^31 / 512 B = 4,194,304 and 2^32 / 512 B = 8,388,608 (MLP rows); 2^32 / 128 B = 33.5 M is beyond the table (GMF rows)
+    users = np.array([0, 123_457, 4_194_303, 4_194_304, 5_000_001, 8_388_607, 8_388_608, 9_999_999], np.int64)
+    ut = torch.from_numpy(users).to(dev)
+    ids, vals = tower.score_topk(ut, K)
+    # the id-range form over the table's last rows agrees with the id-list form
+    ids_r, vals_r = tower.score_topk((U - 3, 3), K)
+    assert torch.equal(ids_r[2], ids[7]) and torch.equal(vals_r[2], vals[7])
+
+    if "sd" not in _cfg5_ref:       # the reference's ops on the host, once for both precisions
+        sd = {"embed_user_GMF.weight": ug[ut].cpu(), "embed_item_GMF.weight": ig.cpu(),
+              "embed_user_MLP.weight": um[ut].cpu(), "embed_item_MLP.weight": im.cpu()}
+        sd.update({k: v.detach().clone() for k, v in small.state_dict().items() if "embed" not in k})
+        items = torch.arange(I)
+        _cfg5_ref["sd"] = sd
+        _cfg5_ref["scores"] = np.stack([T.ncf_forward(sd, torch.full((I,), r, dtype=torch.int64), items).numpy() for r in range(len(users))])
+    ref = _cfg5_ref["scores"]
+    oid, oval = O.topk_rows(ref, K)
+    assert_close(vals.cpu().numpy(), oval, what="cfg5 (10 M-row tables) top-100 scores")
+    got_ids = ids.cpu().numpy()
+    diff = got_ids != oid
+    if diff.any():                  # ids may differ only where the reference's scores tie within tolerance
+        r, c = np.where(diff)
+        gap = np.abs(ref[r, got_ids[r, c]] - oval[r, c])
+        assert (gap <= 1e-5 * np.abs(oval[r, c]) + 1e-6).all()
+    assert diff.mean() < 0.01
+
+    # pair path with the same far-apart user ids (64-bit row offsets in tower_pairs_kernel)
+    rng = np.random.default_rng(11)
+    pu = np.repeat(np.arange(len(users)), 512)
+    pi = rng.integers(0, I, pu.size)
+    s = tower.score_pairs(torch.from_numpy(users[pu]).to(dev), torch.from_numpy(pi).to(dev))
+    assert_close(s.cpu().numpy(), ref[pu, pi], what="cfg5 pair path at 10 M-row tables")
+    # and an id one past the end is reported, not read
+    with pytest.raises(IndexError):
+        tower.score_pairs(torch.tensor([U], device=dev), torch.tensor([0], device=dev))

@@ -234,6 +234,35 @@ def test_topk_properties_long_rows_and_masks():
         assert np.array_equal(vals.cpu().numpy(), oval, equal_nan=True)
 
 
+def test_topk_seen_mask_from_the_rating_matrix_and_user_selection():
+    """reco_topk_rows_seen: helper.py:272,313,335 with the mask read off the float rating matrix and users picked by id."""
+    from recommender_amd import ops
+    rng = np.random.default_rng(12)
+    for U, N, k, ld_pad in ((97, 3706, 10, 6), (5, 70001, 100, 0), (33, 131, 128, 1), (2, 1, 1, 0)):
+        sc = np.clip(rng.standard_normal((U, N)) * 2 + 3, 1.0, 5.0).astype(np.float32)        # clamp plateaus: ties
+        R = ((rng.random((U, N)) < 0.2) * rng.integers(1, 6, (U, N))).astype(np.float32)
+        R[rng.random((U, N)) < 0.01] = -1.0                          # not > 0: not seen
+        buf = torch.zeros((U, N + ld_pad), dtype=torch.float32, device="cuda")
+        buf[:, :N] = torch.from_numpy(sc).cuda()
+        Rt = torch.from_numpy(R).cuda()
+        masked = O.mask_seen(sc, R > 0)
+        oid, oval = O.topk_rows(masked, k)
+        ids, vals = ops.topk_rows_seen(buf[:, :N], k, Rt)
+        assert np.array_equal(ids.cpu().numpy(), oid) and np.array_equal(vals.cpu().numpy(), oval), (U, N, k)
+        ids, vals = ops.topk_rows_seen(buf[:, :N], k, None)          # no mask: plain top-k
+        pid, pval = O.topk_rows(sc, k)
+        assert np.array_equal(ids.cpu().numpy(), pid) and np.array_equal(vals.cpu().numpy(), pval)
+        users = rng.integers(0, U, 19)
+        ids, vals = ops.topk_rows_seen(buf[:, :N], k, Rt, torch.from_numpy(users).cuda())
+        assert np.array_equal(ids.cpu().numpy(), oid[users]) and np.array_equal(vals.cpu().numpy(), oval[users])
+        ids, vals = ops.topk_rows_seen(buf[:, :N], k, Rt, torch.zeros(0, dtype=torch.int64))
+        assert ids.shape == (0, k)
+        with pytest.raises(IndexError):
+            ops.topk_rows_seen(buf[:, :N], k, Rt, torch.tensor([0, U]))
+        with pytest.raises(ValueError):
+            ops.topk_rows_seen(buf[:, :N], k, Rt[:, : max(N - 1, 0)])
+
+
 def test_gather_kernels():
     from recommender_amd import ops
     rng = np.random.default_rng(5)
