@@ -95,6 +95,28 @@ int reco_linear_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_t 
                     int act, float lo, float hi, float* C, int64_t ldc, int flags,
                     void* ws, size_t ws_bytes, void* stream);
 
+/* Linear layer over a SPARSE input given as CSR -- the "masked-observed" form of the AutoRec / Hybrid encoders, whose input
+ * is the 4.5 %-dense rating matrix (or its transpose) with unobserved entries fed as literal zeros:
+ *   src/autorec/utils/model.py:31-33 with X from src/api/core/inference_engine.py:230 / src/api/core/data_loader.py:96-103;
+ *   src/hybridautorecncf/evaluate_hybridautorecncf_rating.py:78-89 (first encoder layer).
+ *   C[m, :] = act( sum over the nonzeros (k, x) of row m in ascending k of  x * Wt[k, :]  + bias )
+ * row_ptr [M+1] int64, col [nnz] int32 (ascending within a row; values outside [0, K) are clamped, never read out of range),
+ * val [nnz]; Wt = W^T [K, N] row-major with row stride ldwt (reco_transpose_f32 of the nn.Linear weight, once per weight
+ * version).  Zeros contribute nothing to an fp32 sum, so the result is the dense layer's k-ordered fmaf chain without its
+ * zero terms.  The segment table cuts rows into pieces of at most seg_len (<= 256) nonzeros, one workgroup each:
+ *   row_seg_ptr [M+1] int64  first segment of every row (every row owns >= 1 segment, an empty row an empty one),
+ *   seg_row [S] int32, seg_begin [S] int64 (offset of the segment's first nonzero);
+ * rows cut into several segments are summed in segment order by a second launch (deterministic).
+ * ws: reco_csr_linear_workspace_bytes(S, N) (partial sums; unused when S == M). */
+size_t reco_csr_linear_workspace_bytes(int64_t S, int64_t N);
+int reco_csr_linear_f32(const int64_t* row_ptr, const int32_t* col, const float* val, int64_t M, int64_t K,
+                        const int64_t* row_seg_ptr, const int32_t* seg_row, const int64_t* seg_begin, int64_t S, int seg_len,
+                        const float* Wt, int64_t ldwt, const float* bias, int64_t N,
+                        int act, float lo, float hi, float* C, int64_t ldc, void* ws, size_t ws_bytes, void* stream);
+
+/* out[c, r] = in[r, c]  (weight layout for reco_csr_linear_f32; no counterpart in the reference) */
+int reco_transpose_f32(const float* in, int64_t rows, int64_t cols, int64_t ld_in, float* out, int64_t ld_out, void* stream);
+
 /* AutoRec forward: out = act( sigmoid(X We^T + be) Wd^T + bd )        src/autorec/utils/model.py:31-33
  * X [B, n_in], We [hidden, n_in], Wd [n_in, hidden], hidden_ws [B, hidden] (caller scratch),
  * out [B, n_in].  act = RECO_ACT_NONE (the module's forward) or RECO_ACT_CLAMP with lo/hi

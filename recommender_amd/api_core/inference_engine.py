@@ -119,6 +119,8 @@ class AutoRecInferenceEngine:
         if model is not None and training_tensor is not None:
             user_num = user_num or training_tensor.shape[0]; item_num = item_num or training_tensor.shape[1]
             if self.item_based:
+                if training_tensor.is_cuda:
+                    model.attach_ratings(training_tensor)                       # N2: the matrix stays sparse (CSR) on the device
                 model.cache_hidden(training_tensor)                             # H = sigmoid(enc(X^T)), once at start-up
         self.config = {"user_num": user_num, "item_num": item_num}
 

@@ -16,6 +16,11 @@ import torch.nn as nn
 from ... import ops
 
 _dev_cache = weakref.WeakKeyDictionary()
+_csr_cache = weakref.WeakKeyDictionary()         # model -> (key of the attached rating matrix, ops.CsrMatrix of the encoder's batch)
+
+
+def _matrix_key(t):
+    return (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
 
 
 class AutoRec(nn.Module):
@@ -43,6 +48,39 @@ class AutoRec(nn.Module):
     def _device_of(x):
         ops.require_gpu()
         return x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device())
+
+    # -- N2: the rating matrix kept sparse on the device ------------------------------------------------------
+    def attach_ratings(self, train_matrix):
+        """Builds (once) the CSR form of the encoder's batch for this [users, items] rating matrix -- for the item-based
+        model the transposed matrix, row i = item i's ratings -- and keeps it on the device.  Every later call that is
+        handed the same tensor (reconstruct_all, recommend_topk, cache_hidden) then runs the encoder over the observed
+        entries only (reco_csr_linear_f32); zeros contribute nothing to an fp32 sum, so the result is the dense layer's with
+        its zero terms left out.  Replaces the dense float matrix that src/api/core/data_loader.py:96-103,149-161 builds and
+        ships to the device as the encoder's only input form.  Returns the CsrMatrix."""
+        device = self._device_of(train_matrix)
+        m = train_matrix.to(device=device, dtype=torch.float32).contiguous()
+        csr = ops.CsrMatrix.from_dense(m, transpose=self.item_based)
+        _csr_cache[self] = (_matrix_key(m), csr)
+        return csr
+
+    def _attached(self, m):
+        hit = _csr_cache.get(self)
+        return hit[1] if hit is not None and hit[0] == _matrix_key(m) else None
+
+    def _encoder_t(self, device):
+        """encoder weight as [n_in, hidden] (the sparse kernel reads one contiguous row per observed entry), per weight version"""
+        _, (we, be, wd, bd), extra = self._weights(device)
+        if "WeT" not in extra:
+            extra["WeT"] = ops.transpose(we)
+        return extra["WeT"]
+
+    def _hidden_of(self, m, device):
+        """H = sigmoid(encoder(batch)) [items, hidden] for the item-based model and the [users, items] matrix m."""
+        we, be, wd, bd = self._weights(device)[1]
+        csr = self._attached(m)
+        if csr is not None:
+            return ops.csr_linear(csr, self._encoder_t(device), be, act="sigmoid")
+        return ops.linear(m, we, be, act="sigmoid", x_transposed=True)
 
     # -- reference interface ----------------------------------------------------------------------------------
     def forward(self, input_data: torch.Tensor) -> torch.Tensor:
@@ -73,11 +111,18 @@ class AutoRec(nn.Module):
         device = self._device_of(train_matrix)
         m = train_matrix.to(device=device, dtype=torch.float32).contiguous()
         if not self.item_based:
-            return self.reconstruct(m, clamp)
-        # no transposed copies: the encoder reads R as the [K = users, M = items] operand, and the decoder is run with
-        # its operands swapped, R_hat^T[u, i] = Wd[u, :] . H[i, :] + bd[u], which lands directly in [users, items]
+            csr = self._attached(m)
+            if csr is None:
+                return self.reconstruct(m, clamp)
+            we, be, wd, bd = self._weights(device)[1]
+            h = ops.csr_linear(csr, self._encoder_t(device), be, act="sigmoid")
+            act = (None, 0.0, 0.0) if clamp is None else ("clamp", float(clamp[0]), float(clamp[1]))
+            return ops.linear(h, wd, bd, act=act[0], lo=act[1], hi=act[2])
+        # no transposed copies: the encoder reads R as the [K = users, M = items] operand (or, with attach_ratings, only its
+        # observed entries), and the decoder is run with its operands swapped, R_hat^T[u, i] = Wd[u, :] . H[i, :] + bd[u],
+        # which lands directly in [users, items]
         we, be, wd, bd = self._weights(device)[1]
-        h = ops.linear(m, we, be, act="sigmoid", x_transposed=True)
+        h = self._hidden_of(m, device)
         act = (None, 0.0, 0.0) if clamp is None else ("clamp", float(clamp[0]), float(clamp[1]))
         # rows padded to whole 128-byte lines (3706 -> 3712 floats): aligned stores in the GEMM epilogue, float4 reads in the
         # top-k scan; the result is the [users, items] view of that buffer
@@ -105,7 +150,7 @@ class AutoRec(nn.Module):
         device = self._device_of(train_matrix)
         sig, (we, be, wd, bd), extra = self._weights(device)
         x = train_matrix.to(device=device, dtype=torch.float32).contiguous()
-        extra["H"] = ops.linear(x, we, be, act="sigmoid", x_transposed=True)
+        extra["H"] = self._hidden_of(x, device)
         return extra["H"]
 
     def predict_user(self, user_id, item_ids=None, clamp=(1.0, 5.0)):

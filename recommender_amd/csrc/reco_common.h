@@ -79,3 +79,11 @@ int launch_topk_rows_ex(const float* scores, int64_t rows, int64_t N, int64_t ld
                         const int64_t* row_ids, int64_t src_rows, int32_t* oob, int32_t* out_ids, float* out_vals,
                         void* ws, size_t ws_bytes, hipStream_t s);
 size_t topk_workspace_bytes(int64_t rows, int64_t N, int k);
+
+// sparse.hip
+int launch_csr_linear(const int64_t* row_ptr, const int32_t* col, const float* val, int64_t M, int64_t K,
+                      const int64_t* row_seg_ptr, const int32_t* seg_row, const int64_t* seg_begin, int64_t S, int seg_len,
+                      const float* Wt, int64_t ldwt, const float* bias, int64_t N, int act, float lo, float hi,
+                      float* C, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t s);
+size_t csr_linear_workspace_bytes(int64_t S, int64_t N);
+int launch_transpose(const float* in, int64_t rows, int64_t cols, int64_t ldi, float* out, int64_t ldo, hipStream_t s);

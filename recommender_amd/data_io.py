@@ -34,12 +34,10 @@ def read_ratings_dat(path):
     return t[:, 0].astype(np.int32), t[:, 1].astype(np.int32), t[:, 2].astype(np.float32)
 
 
-def build_rating_matrix(users, items, ratings, user_num, item_num):
-    """Dense [user_num, item_num] float32 matrix exactly as _create_matrix_from_ratings (data_loader.py:72-110):
-
-    each id space is re-indexed to 0..n-1 in sorted order unless it already is exactly that; entries whose new ids fall
-    outside the matrix are dropped; for a repeated (user, item) the LAST occurrence wins.
-    """
+def rating_triplets(users, items, ratings, user_num, item_num):
+    """(user, item, rating) of the entries _create_matrix_from_ratings (data_loader.py:72-110) writes into its matrix, in file
+    order: each id space is re-indexed to 0..n-1 in sorted order unless it already is exactly that; entries whose new ids fall
+    outside the matrix are dropped.  (A repeated (user, item) is resolved by whoever consumes the triplets: last one wins.)"""
     users = np.asarray(users); items = np.asarray(items); ratings = np.asarray(ratings, np.float32)
 
     def reindex(ids):
@@ -48,15 +46,49 @@ def build_rating_matrix(users, items, ratings, user_num, item_num):
 
     u = reindex(users); i = reindex(items)
     keep = (u >= 0) & (u < user_num) & (i >= 0) & (i < item_num)
+    return u[keep], i[keep], ratings[keep]
+
+
+def build_rating_matrix(users, items, ratings, user_num, item_num):
+    """Dense [user_num, item_num] float32 matrix exactly as _create_matrix_from_ratings (data_loader.py:72-110); for a
+    repeated (user, item) the LAST occurrence wins."""
+    u, i, r = rating_triplets(users, items, ratings, user_num, item_num)
     mat = np.zeros((user_num, item_num), np.float32)
-    mat[u[keep], i[keep]] = ratings[keep]                    # repeated indices: numpy assigns in order, the last one stays
+    mat[u, i] = r                                            # repeated indices: numpy assigns in order, the last one stays
     return mat
+
+
+def csr_arrays(rows, cols, vals, n_rows, n_cols):
+    """(row_ptr int64 [n_rows + 1], col int32 [nnz], val float32 [nnz]) of the matrix the triplets describe: sorted by
+    (row, col), the LAST occurrence of a repeated (row, col) kept, zeros dropped.  Host-side half of the sparse device layout
+    (SURVEY N2); ops.CsrMatrix.from_triplets uploads it and adds the kernel's segment table."""
+    rows = np.asarray(rows, np.int64); cols = np.asarray(cols, np.int64); vals = np.asarray(vals, np.float32)
+    key = rows * int(n_cols) + cols
+    order = np.argsort(key, kind="stable")
+    key = key[order]
+    last = np.ones(len(key), bool)
+    last[:-1] = key[1:] != key[:-1]
+    keep = last & (vals[order] != 0)
+    r = rows[order][keep]
+    row_ptr = np.zeros(int(n_rows) + 1, np.int64)
+    np.cumsum(np.bincount(r, minlength=int(n_rows)), out=row_ptr[1:])
+    return row_ptr, cols[order][keep].astype(np.int32), vals[order][keep]
 
 
 def load_training_matrix(ratings_path, user_num=6040, item_num=3706):
     """data_loader.load_training_matrix for the ratings.dat branch (:29-32)."""
     u, i, r = read_ratings_dat(ratings_path)
     return build_rating_matrix(u, i, r, user_num, item_num)
+
+
+def load_training_csr(ratings_path, user_num=6040, item_num=3706, item_major=False):
+    """The same matrix as load_training_matrix, never densified: CSR arrays of the [users, items] matrix, or with
+    item_major=True of its transpose (row i = item i's ratings from all users: the item-based AutoRec's batch,
+    inference_engine.py:230)."""
+    u, i, r = rating_triplets(*read_ratings_dat(ratings_path), user_num, item_num)
+    if item_major:
+        return csr_arrays(i, u, r, item_num, user_num)
+    return csr_arrays(u, i, r, user_num, item_num)
 
 
 def read_pairs_tsv(path):

@@ -141,6 +141,103 @@ def linear(x, weight, bias=None, act=None, lo=0.0, hi=0.0, out=None, x_transpose
     return out
 
 
+def transpose(x):
+    """x.T as a new contiguous tensor (HIP kernel; used for the [K, N] weight layout of csr_linear)."""
+    x = _f32(x, "input", 2)
+    out = torch.empty((x.shape[1], x.shape[0]), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().reco_transpose_f32(_p(x), x.shape[0], x.shape[1], x.shape[1], _p(out), x.shape[0], _stream(x.device)))
+    return out
+
+
+class CsrMatrix:
+    """A float32 matrix kept SPARSE on the device: CSR arrays plus the segment table of the sparse Linear kernel.
+
+    Built once per rating matrix (start-up work, like packing weights), from a dense tensor or from (row, col, value)
+    triplets; the scoring path then never touches the zeros.  `shape` = (rows, cols).
+    """
+    SEG_LEN = 256
+
+    def __init__(self, row_ptr, col, val, shape):
+        dev = val.device
+        if not val.is_cuda:
+            raise ValueError("CsrMatrix lives on the GPU")
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.row_ptr = row_ptr.to(device=dev, dtype=torch.int64).contiguous()
+        self.col = col.to(device=dev, dtype=torch.int32).contiguous()
+        self.val = val.to(dtype=torch.float32).contiguous()
+        if self.row_ptr.numel() != self.shape[0] + 1 or self.col.numel() != self.val.numel():
+            raise ValueError("CsrMatrix: row_ptr has %d entries for %d rows; col / val have %d / %d entries"
+                             % (self.row_ptr.numel(), self.shape[0], self.col.numel(), self.val.numel()))
+        self.nnz = int(self.val.numel())
+        # segment table: row r owns max(1, ceil(nnz_r / SEG_LEN)) segments
+        cnt = self.row_ptr[1:] - self.row_ptr[:-1]
+        segs = torch.clamp((cnt + self.SEG_LEN - 1) // self.SEG_LEN, min=1)
+        self.row_seg_ptr = torch.zeros(self.shape[0] + 1, dtype=torch.int64, device=dev)
+        self.row_seg_ptr[1:] = torch.cumsum(segs, 0)
+        rows = torch.arange(self.shape[0], device=dev, dtype=torch.int64)
+        seg_row = torch.repeat_interleave(rows, segs)
+        self.n_seg = int(seg_row.numel())
+        within = torch.arange(self.n_seg, device=dev, dtype=torch.int64) - self.row_seg_ptr[seg_row]
+        self.seg_begin = (self.row_ptr[seg_row] + within * self.SEG_LEN).contiguous()
+        self.seg_row = seg_row.to(torch.int32).contiguous()
+        self.device = dev
+
+    @classmethod
+    def from_dense(cls, m, transpose=False):
+        """CSR of m (or of m.T) for a dense [rows, cols] device tensor; entries != 0 are kept."""
+        m = _f32(m, "matrix", 2)
+        v = m.t() if transpose else m
+        idx = v.nonzero()                                   # sorted by (row, col)
+        counts = torch.bincount(idx[:, 0], minlength=v.shape[0])
+        row_ptr = torch.zeros(v.shape[0] + 1, dtype=torch.int64, device=m.device)
+        row_ptr[1:] = torch.cumsum(counts, 0)
+        return cls(row_ptr, idx[:, 1], v[idx[:, 0], idx[:, 1]], v.shape)
+
+    @classmethod
+    def from_triplets(cls, rows, cols, vals, shape, device):
+        """CSR from host (row, col, value) triplets; for a repeated (row, col) the LAST occurrence wins
+        (data_loader.py:96-103 assigns in file order), zeros are dropped."""
+        from .data_io import csr_arrays
+        row_ptr, c, v = csr_arrays(rows, cols, vals, shape[0], shape[1])
+        dev = torch.device(device)
+        return cls(torch.from_numpy(row_ptr).to(dev), torch.from_numpy(c).to(dev), torch.from_numpy(v).to(dev), shape)
+
+    def to_dense(self):
+        out = torch.zeros(self.shape, dtype=torch.float32, device=self.device)
+        rows = torch.repeat_interleave(torch.arange(self.shape[0], device=self.device), self.row_ptr[1:] - self.row_ptr[:-1])
+        out[rows, self.col.long()] = self.val
+        return out
+
+
+def csr_linear(x, weight_t, bias=None, act=None, lo=0.0, hi=0.0, out=None):
+    """act(x @ weight_t + bias) for a CsrMatrix x [M, K] and weight_t = W.T [K, N] (see `transpose`): only the nonzeros of x
+    are visited (reco_csr_linear_f32)."""
+    if not isinstance(x, CsrMatrix):
+        raise TypeError("x must be a CsrMatrix")
+    weight_t = _f32(weight_t, "weight_t", 2)
+    M, K = x.shape
+    N = weight_t.shape[1]
+    if weight_t.shape[0] != K or weight_t.device != x.device:
+        raise ValueError("weight_t must be a [%d, N] float32 tensor on %s, got %s on %s" % (K, x.device, tuple(weight_t.shape), weight_t.device))
+    if bias is not None:
+        bias = _f32(bias, "bias", 1)
+        if bias.numel() != N or bias.device != x.device:
+            raise ValueError("bias has %d entries, expected %d" % (bias.numel(), N))
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    else:
+        _check_out(out, (M, N), torch.float32, x.device, "out", rows_may_be_strided=True)
+    L = _lib.lib()
+    nbytes = L.reco_csr_linear_workspace_bytes(x.n_seg, N) if x.n_seg > M else 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
+    with torch.cuda.device(x.device):
+        check(L.reco_csr_linear_f32(_p(x.row_ptr), _p(x.col), _p(x.val), M, K, _p(x.row_seg_ptr), _p(x.seg_row), _p(x.seg_begin),
+                                    x.n_seg, CsrMatrix.SEG_LEN, _p(weight_t), N, _p(bias), N, ACTS[act], lo, hi,
+                                    _p(out), out.stride(0) if M > 1 else N, _p(ws), nbytes, _stream(x.device)))
+    return out
+
+
 def autorec_forward(x, we, be, wd, bd, clamp=None, precision=None):
     """decoder(sigmoid(encoder(x))) (+clamp) -- src/autorec/utils/model.py:31-33, inference_engine.py:232."""
     x = _f32(x, "input", 2)

@@ -24,6 +24,26 @@ def test_ratings_dat_to_dense_matrix(g6):
     assert m3.shape == (2, 2) and m3.sum() == 7
 
 
+def test_ratings_dat_to_csr_equals_the_reference_loaders_dense_matrix(g6):
+    """N2: the sparse layout describes exactly the matrix the reference's loader built (re-indexing, last duplicate wins)."""
+    user_num, item_num = (int(v) for v in g6["cfg"])
+    ref = g6["ratings_matrix"]
+    for item_major in (False, True):
+        row_ptr, col, val = D.load_training_csr(os.path.join(FILES, "mini_ratings.dat"), user_num, item_num, item_major)
+        want = ref.T if item_major else ref
+        assert row_ptr.dtype == np.int64 and col.dtype == np.int32 and val.dtype == np.float32
+        assert len(row_ptr) == want.shape[0] + 1 and row_ptr[0] == 0 and row_ptr[-1] == len(col) == len(val) == (want != 0).sum()
+        dense = np.zeros_like(want)
+        for r in range(want.shape[0]):
+            c = col[row_ptr[r]:row_ptr[r + 1]]
+            assert (np.diff(c) > 0).all()                              # ascending, no duplicates within a row
+            dense[r, c] = val[row_ptr[r]:row_ptr[r + 1]]
+        assert np.array_equal(dense, want)
+    # duplicates: the last occurrence wins; explicit zeros are dropped; empty rows get empty ranges
+    rp, c, v = D.csr_arrays([2, 0, 2, 2, 0], [1, 3, 1, 0, 2], [5., 1., 4., 0., 2.], 4, 4)
+    assert rp.tolist() == [0, 2, 2, 3, 3] and c.tolist() == [2, 3, 1] and v.tolist() == [2., 1., 4.]
+
+
 def test_train_rating_and_test_negative(g6, tmp_path):
     pairs = D.read_pairs_tsv(os.path.join(FILES, "mini.train.rating"))
     assert np.array_equal(pairs, g6["train_data"])

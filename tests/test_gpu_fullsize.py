@@ -138,6 +138,15 @@ def test_cfg3_autorec_full_reconstruction_and_masked_topk(tower_precision):
     oid, oval = O.topk_rows(O.mask_seen(np.ascontiguousarray(pred), train > 0), 10)
     assert np.array_equal(vals.cpu().numpy(), oval)
     assert np.array_equal(ids.cpu().numpy(), oid)                  # clamp plateaus: ties resolved by ascending item id
+    # N2: the same with the rating matrix kept sparse on the device (encoder over the 1.0 M observed entries only)
+    tr = torch.from_numpy(train).cuda()
+    csr = m.attach_ratings(tr)
+    assert csr.shape == (3706, 6040) and csr.nnz == int((train != 0).sum())
+    pred_s = m.reconstruct_all(tr).cpu().numpy()
+    assert_close(pred_s, np.clip(ref, 1.0, 5.0).T, atol=4e-6, what="cfg3 reconstruct_all (sparse encoder) vs torch CPU")
+    ids_s, vals_s = m.recommend_topk(tr, 10)
+    oid_s, oval_s = O.topk_rows(O.mask_seen(np.ascontiguousarray(pred_s), train > 0), 10)
+    assert np.array_equal(vals_s.cpu().numpy(), oval_s) and np.array_equal(ids_s.cpu().numpy(), oid_s)
 
 
 def test_cfg4_hybrid_full_catalog(tower_precision):

@@ -263,6 +263,91 @@ def test_topk_seen_mask_from_the_rating_matrix_and_user_selection():
             ops.topk_rows_seen(buf[:, :N], k, Rt[:, : max(N - 1, 0)])
 
 
+def test_sparse_linear_over_csr_input(tower_precision):
+    """reco_csr_linear_f32: the encoder layer over the observed entries only equals the dense layer (zeros add nothing)."""
+    from recommender_amd import ops
+    rng = np.random.default_rng(21)
+    for M, K, N, dens, act in ((67, 300, 500, 0.05, "sigmoid"), (5, 6040, 256, 0.5, "relu"), (40, 97, 37, 0.3, None),
+                               (3, 1000, 1030, 0.9, "sigmoid"), (9, 11, 2, 0.0, None)):
+        X = ((rng.random((M, K)) < dens) * rng.integers(1, 6, (M, K))).astype(np.float32)
+        if dens > 0:
+            X[0] = rng.integers(1, 6, K)                    # a fully observed row: several segments
+            X[M - 1] = 0                                    # an empty row
+        W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32); b = rng.standard_normal(N).astype(np.float32)
+        Xd = torch.from_numpy(X).cuda(); Wd = torch.from_numpy(W).cuda(); bd = torch.from_numpy(b).cuda()
+        csr = ops.CsrMatrix.from_dense(Xd)
+        assert csr.nnz == int((X != 0).sum()) and torch.equal(csr.to_dense(), Xd)
+        if dens > 0 and K > ops.CsrMatrix.SEG_LEN:
+            assert csr.n_seg > M                             # the full row was cut into segments
+        Wt = ops.transpose(Wd)
+        assert torch.equal(Wt, Wd.t().contiguous())
+        got = ops.csr_linear(csr, Wt, bd, act).cpu().numpy()
+        pre64 = X.astype(np.float64) @ W.astype(np.float64).T + b
+        ref64 = {"sigmoid": lambda v: 1 / (1 + np.exp(-v)), "relu": lambda v: np.maximum(v, 0), None: lambda v: v}[act](pre64)
+        # gate: 1e-5 relative + 1e-6 absolute, plus what ANY fp32 summation of that many terms is entitled to: a few ulps of the
+        # sum of the terms' magnitudes (the fully observed 6,040-entry row sums ~190 in magnitude to reach values of ~0.04; all
+        # three activations are 1-Lipschitz, so the bound carries over)
+        slack = 2e-7 * (np.abs(X).astype(np.float64) @ np.abs(W).astype(np.float64).T + np.abs(b))
+        for name, other in (("fp64", ref64), ("the dense MFMA layer", ops.linear(Xd, Wd, bd, act, precision="f32").cpu().numpy())):
+            err = np.abs(got - other)
+            tol = 1e-5 * np.maximum(np.abs(got), np.abs(other)) + 1e-6 + slack
+            assert (err <= tol).all(), "csr_linear vs %s (%d,%d,%d): worst err/tol %.2f" % (name, M, K, N, (err / tol).max())
+        sparse_rows = (X != 0).sum(1) < 400                         # rows like the real matrix's: the plain gate, no slack
+        if sparse_rows.any():
+            assert_close(got[sparse_rows], ref64[sparse_rows], atol=2e-6, what="csr_linear, sparse rows vs fp64")
+        # the transposed matrix from the same dense tensor, and from host triplets with a duplicate
+        csr_t = ops.CsrMatrix.from_dense(Xd, transpose=True)
+        assert torch.equal(csr_t.to_dense(), Xd.t())
+        r, c = np.nonzero(X)
+        trip = ops.CsrMatrix.from_triplets(np.concatenate([r[:1], r]), np.concatenate([c[:1], c]),
+                                           np.concatenate([[9.0], X[r, c]]) if len(r) else X[r, c], (M, K), "cuda")
+        assert torch.equal(trip.to_dense(), Xd)
+        # determinism
+        assert np.array_equal(ops.csr_linear(csr, Wt, bd, act).cpu().numpy(), got)
+    with pytest.raises(ValueError):
+        ops.csr_linear(csr, Wt[:, :1].contiguous().t().contiguous(), None)
+
+
+def test_autorec_and_hybrid_with_the_rating_matrix_kept_sparse(g3, g4, tower_precision):
+    """attach_ratings: same outputs as the dense path and as the reference-generated fixtures."""
+    from recommender_amd.autorec.utils.model import AutoRec
+    from recommender_amd.hybridautorecncf.model import HybridAutoRecNCF
+    for tag, (U, I, H) in (("a", (193, 89, 64)), ("b", (61, 37, 500))):
+        m = AutoRec(U, I, H, True)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in golden_sd(g3, tag).items()})
+        m = m.eval().cuda()
+        train = torch.from_numpy(g3[tag + "__train"].astype(np.float32)).cuda()
+        atol = 2.0 * float(np.abs(g3[tag + "__raw"] - g3[tag + "__raw64"]).max())
+        dense_all = m.reconstruct_all(train).cpu().numpy()
+        dense_ids, dense_vals = m.recommend_topk(train, 10)
+        csr = m.attach_ratings(train)
+        assert csr.shape == (I, U) and csr.nnz == int((g3[tag + "__train"] != 0).sum())
+        sparse_all = m.reconstruct_all(train).cpu().numpy()
+        assert_close(sparse_all, g3[tag + "__clamped"].T, atol=atol, what=tag + " reconstruct_all (sparse encoder) vs golden")
+        assert_close(sparse_all, dense_all, atol=atol, what=tag + " sparse vs dense encoder")
+        ids, vals = m.recommend_topk(train, 10)
+        ref_ids = g3[tag + "__top10"].astype(np.int64)
+        assert_close(vals.cpu().numpy(), np.take_along_axis(g3[tag + "__masked"], ref_ids, 1), atol=atol, what=tag + " top-10 (sparse)")
+        m.cache_hidden(train)
+        assert_close(m.predict_user(7).cpu().numpy(), g3[tag + "__clamped"][:, 7], atol=atol, what="predict_user (sparse H)")
+        # a different tensor with the same values is NOT the attached one: dense path, same numbers
+        assert_close(m.reconstruct_all(train.clone()).cpu().numpy(), dense_all, atol=0, rtol=0, what="clone takes the dense path")
+        # an in-place edit bumps the version: the stale CSR is not used
+        train[0, 0] += 1.0
+        again = m.reconstruct_all(train).cpu().numpy()
+        assert not np.array_equal(again, sparse_all)
+    for tag, rating, (U, I), hd in (("rating", True, (83, 47), (48, 40)), ("logit", False, (40, 26), (256, 128))):
+        m = HybridAutoRecNCF(U, I, 64, [128, 64], hidden_dims=hd, rating_output=rating)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in golden_sd(g4, tag).items()})
+        m = m.eval().cuda()
+        R = torch.from_numpy(g4[tag + "__R"].astype(np.float32)).cuda()
+        cu, ci = m.attach_ratings(R)
+        assert cu.shape == (U, I) and ci.shape == (I, U)
+        assert_close(m.user_autorec.encode(cu).cpu().numpy(), g4[tag + "__zu"], atol=2e-6, what=tag + " zu (sparse)")
+        assert_close(m.item_autorec.encode(ci).cpu().numpy(), g4[tag + "__zi"], atol=2e-6, what=tag + " zi (sparse)")
+        assert_close(m.score_all(R).cpu().numpy(), g4[tag + "__pred"], atol=2e-6, what=tag + " score_all (sparse encoders)")
+
+
 def test_gather_kernels():
     from recommender_amd import ops
     rng = np.random.default_rng(5)

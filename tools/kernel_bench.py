@@ -81,6 +81,18 @@ def bench_autorec():
     ms = timeit(lambda: m.recommend_topk(R, 10))
     emit("AutoRec cfg3 end to end (reconstruct_all + seen-mask + top-10)", "R[6040,3706]", ms, "mfma", 2 * 2 * 3706 * 6040 * 500,
          "44.77 GFLOP per full reconstruction", "users/s = %.3g" % (6040 / ms * 1e3))
+    m.attach_ratings(R)
+    ms = timeit(lambda: m.recommend_topk(R, 10))
+    emit("AutoRec cfg3 end to end, rating matrix kept sparse (CSR encoder + dense decoder + seen-mask + top-10)", "R[6040,3706] %.1f %% dense" % (100 * float((R != 0).float().mean())),
+         ms, "mfma", 2 * 2 * 3706 * 6040 * 500, "44.77 GFLOP algorithmic (the encoder executes 2*nnz*500)", "users/s = %.3g" % (6040 / ms * 1e3))
+    csr = ops.CsrMatrix.from_dense(R, transpose=True)
+    wet = ops.transpose(m.encoder[0].weight.detach())
+    ms = timeit(lambda: ops.csr_linear(csr, wet, m.encoder[0].bias.detach(), "sigmoid"))
+    emit("csr_linear_kernel (AutoRec encoder over observed entries)", "M=3706 K=6040 N=500 nnz=%d segs=%d" % (csr.nnz, csr.n_seg), ms, "hbm",
+         csr.nnz * (500 * 4 + 8) + 3706 * 500 * 4, "nnz * (2000 B weight row + 8 B entry) + output; weight rows come from L2 / Infinity Cache, not HBM",
+         "dense MFMA form of the same layer: see the encoder lines below; equivalent dense rate = %.1f TFLOP/s" % (2 * 3706 * 6040 * 500 / ms / 1e9))
+    import recommender_amd.autorec.utils.model as _am
+    _am._csr_cache.pop(m, None)
     we, be = m.encoder[0].weight.detach(), m.encoder[0].bias.detach()
     wd, bd = m.decoder[0].weight.detach(), m.decoder[0].bias.detach()
     h = ops.linear(X, we, be, "sigmoid")
@@ -150,6 +162,10 @@ def bench_tower():
     ms = timeit(lambda: (h.user_autorec.encode(R), h.item_autorec.encode(R, transposed=True)), reps=10)
     emit("hybrid encoders only (6 linear_kernel launches + split-K reduces)", "R[6040,3706] -> zu[6040,64], zi[3706,64]", ms, "mfma", 23.72e9,
          "23.72 GFLOP", "score_all = this + the head below: nothing else runs per call")
+    h.attach_ratings(R)
+    ms = timeit(lambda: h.score_all(R), reps=10)
+    emit("hybrid score_all, rating matrix kept sparse (CSR first encoder layers)", "6040 x 3706", ms, "mfma", 6040 * 3706 * HYBRID_EXEC + 23.72e9,
+         "16,832 FLOP/pair executed + 23.72 GFLOP encoders (algorithmic)", "pairs/s = %.3g" % (6040 * 3706 / ms * 1e3), 6040 * 3706 * HYBRID_ALG + 23.72e9)
     zu = h.user_autorec.encode(R); zi = h.item_autorec.encode(R.t().contiguous())
     ms = timeit(lambda: h.ncf.score_matrix(zu, zi), reps=10)
     emit("tower_tile_kernel<64,false> (+projections)", "6040 x 3706", ms, "mfma", 6040 * 3706 * HYBRID_EXEC, "16,832 FLOP/pair executed", "", 6040 * 3706 * HYBRID_ALG)
