@@ -305,7 +305,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
 // LDS staging area.  The layer-1 activations are staged one K half at a time (tower_shared.h): the first half before quad 0,
 // the second -- into the same 8.7 KB -- right before quad 8 is read (LDS operations of one wave execute in issue order, so the
 // overwrite needs no barrier).  With half rows 8 waves fit next to the image (148 KB): 2 waves per SIMD.
-template <int G, bool L3, int WAVES>
+template <int G, bool L3, int WAVES, bool BIG>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_kernel(PairArgs a)
 {
     constexpr int GS = G + 4;
@@ -331,11 +331,16 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_kernel(Pair
     f32x4 pf[8], qf[8], ps[8], qs[8];                     // first / second K half of the next group's P and Q rows
     f32x4 gu[NG], gi[NG];
     int nu = 0, ni = 0;                                   // the next group's ids (lanes 0..31)
+    // The ids run TWO groups ahead of the MFMAs: a group's row loads are issued from ids that are already in registers, and
+    // the id loads of the group after it fly under a whole group of MFMAs.  (Loaded where they are needed, each id load was an
+    // exposed global round trip at the top of every group: the row addresses depend on it.)
+    int64_t ru = 0, ri = 0;                               // raw ids of the group after next (lanes 0..31)
     if (grp < ngroups) {
         pair_ids(a, grp * 32, lane, nu, ni);
-        pair_load_half(a, nu, ni, lane, 0, pf, qf);
-        pair_load_half(a, nu, ni, lane, 1, ps, qs);
-        if constexpr (G > 0) pair_load_gmf<G>(a, nu, ni, lane, gu, gi);
+        pair_load_half<BIG>(a, nu, ni, lane, 0, pf, qf);
+        pair_load_half<BIG>(a, nu, ni, lane, 1, ps, qs);
+        if constexpr (G > 0) pair_load_gmf<G, BIG>(a, nu, ni, lane, gu, gi);
+        if (grp + stride < ngroups) pair_ids_raw(a, (grp + stride) * 32, lane, ru, ri);
     }
     for (; grp < ngroups; grp += stride) {
         const int64_t base = grp * 32;
@@ -346,9 +351,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_kernel(Pair
         // the second half (ps / qs) still belongs to THIS group: the next group's ids wait in other registers until it is stored
         int nu2 = 0, ni2 = 0;
         if (more) {
-            pair_ids(a, (grp + stride) * 32, lane, nu2, ni2);
-            pair_load_half(a, nu2, ni2, lane, 0, pf, qf);                  // in flight under the MFMAs
-            if constexpr (G > 0) pair_load_gmf<G>(a, nu2, ni2, lane, gu, gi);
+            pair_ids_clamp(a, (grp + stride) * 32, lane, ru, ri, nu2, ni2);     // loaded one group ago
+            pair_load_half<BIG>(a, nu2, ni2, lane, 0, pf, qf);             // in flight under the MFMAs
+            if constexpr (G > 0) pair_load_gmf<G, BIG>(a, nu2, ni2, lane, gu, gi);
+            if (grp + 2 * stride < ngroups) pair_ids_raw(a, (grp + 2 * stride) * 32, lane, ru, ri);
         }
         const float* xrow = s_x + j * HS + 4 * h;
         struct X1Pair {
@@ -365,7 +371,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_kernel(Pair
                 if (q == 8) {                 // quads 0..7 have all been read: stage the second half, refill its registers
                     pair_store_half(s_x, lane, ps, qs);
                     __builtin_amdgcn_wave_barrier();
-                    if (more) pair_load_half(a, nu, ni, lane, 1, ps, qs);
+                    if (more) pair_load_half<BIG>(a, nu, ni, lane, 1, ps, qs);
                 }
             }
             __device__ __forceinline__ f32x4 raw(int q) const { return *reinterpret_cast<const f32x4*>(xrow + 8 * (q & 7)); }
@@ -514,20 +520,28 @@ int launch_tile_t(const TileArgs& a, hipStream_t s)
     return RECO_OK;
 }
 
-template <int G, bool L3>
-int launch_pairs_t(const PairArgs& a, hipStream_t s)
+template <int G, bool L3, bool BIG>
+int launch_pairs_tb(const PairArgs& a, hipStream_t s)
 {
     // 8 waves per workgroup when their half-row staging areas fit next to the image (G <= 32: 148 KB), else 4
     constexpr int WAVES = G <= 32 ? 8 : 4;
     constexpr size_t lds = (size_t)(IMG_SIZE + WAVES * (32 * HS + (G > 0 ? 32 * (G + 4) : 0))) * sizeof(float);
     static_assert(lds <= 160 * 1024, "pair kernel LDS budget");
     static bool attr[RECO_MAX_DEVICES] = {};
-    if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&tower_pairs_kernel<G, L3, WAVES>), lds, attr)) return rc;
+    if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&tower_pairs_kernel<G, L3, WAVES, BIG>), lds, attr)) return rc;
     const int64_t nchunks = ceil_div64(a.B, 32 * WAVES);
     const unsigned grid = (unsigned)(nchunks < 256 ? nchunks : 256);   // persistent: one workgroup per CU
-    hipLaunchKernelGGL((tower_pairs_kernel<G, L3, WAVES>), dim3(grid), dim3(64 * WAVES), lds, s, a);
+    hipLaunchKernelGGL((tower_pairs_kernel<G, L3, WAVES, BIG>), dim3(grid), dim3(64 * WAVES), lds, s, a);
     RECO_CHECK_LAUNCH();
     return RECO_OK;
+}
+
+template <int G, bool L3>
+int launch_pairs_t(const PairArgs& a, hipStream_t s)
+{
+    // 32-bit row offsets (saddr loads) whenever every table is under 2^23 rows; 64-bit offsets otherwise (tower_shared.h)
+    const bool big = a.n_users >= (1ll << 23) || a.n_items >= (1ll << 23);
+    return big ? launch_pairs_tb<G, L3, true>(a, s) : launch_pairs_tb<G, L3, false>(a, s);
 }
 
 }  // namespace

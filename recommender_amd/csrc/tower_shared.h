@@ -282,22 +282,59 @@ __device__ __forceinline__ void pair_ids(const PairArgs& a, int64_t base, int la
     }
 }
 
+// the same in two steps, so that the load can be issued a whole group before its result is needed
+__device__ __forceinline__ void pair_ids_raw(const PairArgs& a, int64_t base, int lane, int64_t& ru, int64_t& ri)
+{
+    const int64_t b = base + (lane & 31);
+    ru = b; ri = b;                                   // identity when no id list is given; also the value past the end (clamped later)
+    if (b < a.B) {
+        if (a.user) ru = a.user[b];
+        if (a.item) ri = a.item[b];
+    }
+}
+
+__device__ __forceinline__ void pair_ids_clamp(const PairArgs& a, int64_t base, int lane, int64_t ru, int64_t ri, int& my_u, int& my_i)
+{
+    const int j = lane & 31, h = lane >> 5;
+    my_u = 0; my_i = 0;
+    if (base + j < a.B) {
+        my_u = (int)clamp_id(ru, a.n_users, h == 0 ? a.oob : nullptr);
+        my_i = (int)clamp_id(ri, a.n_items, h == 0 ? a.oob : nullptr);
+    }
+}
+
+// Row addresses.  BIG = false (every table has fewer than 2^23 rows, i.e. under 4 GiB of 512-byte rows): a row's byte offset
+// fits 32 bits, so a load is "uniform 64-bit base + 32-bit lane offset" -- the saddr form of global_load, one v_mad_u32 per load
+// instead of a sign extension, a 64-bit shift and a 64-bit add (about 100 VALU instructions per group of 32 pairs, each of which
+// costs MFMA issue time).  BIG = true keeps full 64-bit offsets (the 10 M-user tables of cfg5).
+template <bool BIG>
+__device__ __forceinline__ const f32x4* row_chunk(const float* table, int row, int row_floats, int chunk)
+{
+    if constexpr (BIG) return reinterpret_cast<const f32x4*>(table + (int64_t)row * row_floats) + chunk;
+    else {
+        const uint32_t off = (uint32_t)row * (uint32_t)(row_floats * 4) + (uint32_t)(chunk * 16);
+        return reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(table) + off);
+    }
+}
+
+template <bool BIG>
 __device__ __forceinline__ void pair_load_half(const PairArgs& a, int my_u, int my_i, int lane, int half, f32x4* p, f32x4* q)
 {
     const int c = 16 * half + (lane & 15), r = lane >> 4;
     const int u_first = __shfl(my_u, 0);
     if (__ballot(my_u != u_first) == 0) {            // the whole group is one user: its row once (see pair_stage_load)
-        const f32x4 prow = reinterpret_cast<const f32x4*>(a.P + (int64_t)u_first * H1)[c];
+        const f32x4 prow = *row_chunk<BIG>(a.P, u_first, H1, c);
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            p[it] = prow;
-            q[it] = reinterpret_cast<const f32x4*>(a.Q + (int64_t)__shfl(my_i, 4 * it + r) * H1)[c];
+            p[it] = prow;       // (keeping only one copy and branching again at the store was tried: the partially written
+                                //  array stops being promoted to registers and the kernel takes 80 bytes of scratch per lane)
+            q[it] = *row_chunk<BIG>(a.Q, __shfl(my_i, 4 * it + r), H1, c);
         }
     } else {
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            p[it] = reinterpret_cast<const f32x4*>(a.P + (int64_t)__shfl(my_u, 4 * it + r) * H1)[c];
-            q[it] = reinterpret_cast<const f32x4*>(a.Q + (int64_t)__shfl(my_i, 4 * it + r) * H1)[c];
+            p[it] = *row_chunk<BIG>(a.P, __shfl(my_u, 4 * it + r), H1, c);
+            q[it] = *row_chunk<BIG>(a.Q, __shfl(my_i, 4 * it + r), H1, c);
         }
     }
 }
@@ -310,7 +347,7 @@ __device__ __forceinline__ void pair_store_half(float* s_x, int lane, const f32x
         *reinterpret_cast<f32x4*>(s_x + (4 * it + r) * HS + 4 * c) = relu4(p[it] + q[it]);
 }
 
-template <int G>
+template <int G, bool BIG>
 __device__ __forceinline__ void pair_load_gmf(const PairArgs& a, int my_u, int my_i, int lane, f32x4* gu, f32x4* gi)
 {
     constexpr int C = G / 4, NG = (32 * C) / 64;
@@ -318,8 +355,8 @@ __device__ __forceinline__ void pair_load_gmf(const PairArgs& a, int my_u, int m
 #pragma unroll
     for (int it = 0; it < NG; ++it) {
         const int e = it * 64 + lane;
-        gu[it] = reinterpret_cast<const f32x4*>(a.EUg + (int64_t)__shfl(my_u, e / C) * G)[e % C];
-        gi[it] = reinterpret_cast<const f32x4*>(a.EIg + (int64_t)__shfl(my_i, e / C) * G)[e % C];
+        gu[it] = *row_chunk<BIG>(a.EUg, __shfl(my_u, e / C), G, e % C);
+        gi[it] = *row_chunk<BIG>(a.EIg, __shfl(my_i, e / C), G, e % C);
     }
 }
 
