@@ -103,14 +103,21 @@ int reco_linear_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_t 
  * row_ptr [M+1] int64, col [nnz] int32 (ascending within a row; values outside [0, K) are clamped, never read out of range),
  * val [nnz]; Wt = W^T [K, N] row-major with row stride ldwt (reco_transpose_f32 of the nn.Linear weight, once per weight
  * version).  Zeros contribute nothing to an fp32 sum, so the result is the dense layer's k-ordered fmaf chain without its
- * zero terms.  The segment table cuts rows into pieces of at most seg_len (<= 256) nonzeros, one workgroup each:
- *   row_seg_ptr [M+1] int64  first segment of every row (every row owns >= 1 segment, an empty row an empty one),
- *   seg_row [S] int32, seg_begin [S] int64 (offset of the segment's first nonzero);
- * rows cut into several segments are summed in segment order by a second launch (deterministic).
- * ws: reco_csr_linear_workspace_bytes(S, N) (partial sums; unused when S == M). */
+ * zero terms.  The segment table cuts the rows into pieces of at most 256 consecutive nonzeros, one workgroup each:
+ *   row_seg_ptr [M+1] int64   segments of row m are row_seg_ptr[m] .. row_seg_ptr[m+1]-1 (a row without nonzeros has none),
+ *   seg_row [S] int32, seg_begin / seg_end [S] int64 (offsets into col / val);
+ * a row with one segment is finished in place, the partial sums of the others are added in segment order by a second launch
+ * (deterministic; pass single_segment_rows = 1 when EVERY row has exactly one segment: no second launch, no workspace).
+ * order (nullable, int32 [n_order]): the placement table.  Workgroup b runs the segments order[4 b .. 4 b + 3] (negative =
+ * none; RECO_CSR_SEGS_PER_WG = 4 slots per workgroup, one per wave).  The host side uses it for XCD placement: segments are cut
+ * at the boundaries of eight k ranges and every slot of workgroup b holds a segment of range b % 8 -- workgroups b and b + 8
+ * share an XCD on MI355X, so each XCD keeps one eighth of Wt in its own L2 (speed only, never correctness).  NULL: slot = segment.
+ * ws: reco_csr_linear_workspace_bytes(S, N). */
+#define RECO_CSR_SEGS_PER_WG 4
 size_t reco_csr_linear_workspace_bytes(int64_t S, int64_t N);
 int reco_csr_linear_f32(const int64_t* row_ptr, const int32_t* col, const float* val, int64_t M, int64_t K,
-                        const int64_t* row_seg_ptr, const int32_t* seg_row, const int64_t* seg_begin, int64_t S, int seg_len,
+                        const int64_t* row_seg_ptr, const int32_t* seg_row, const int64_t* seg_begin, const int64_t* seg_end,
+                        int64_t S, const int32_t* order, int64_t n_order, int single_segment_rows,
                         const float* Wt, int64_t ldwt, const float* bias, int64_t N,
                         int act, float lo, float hi, float* C, int64_t ldc, void* ws, size_t ws_bytes, void* stream);
 

@@ -155,13 +155,14 @@ extern "C" int reco_autorec_forward(const float* X, int64_t B, const float* We, 
 extern "C" size_t reco_csr_linear_workspace_bytes(int64_t S, int64_t N) { return csr_linear_workspace_bytes(S, N); }
 
 extern "C" int reco_csr_linear_f32(const int64_t* row_ptr, const int32_t* col, const float* val, int64_t M, int64_t K,
-                                   const int64_t* row_seg_ptr, const int32_t* seg_row, const int64_t* seg_begin, int64_t S,
-                                   int seg_len, const float* Wt, int64_t ldwt, const float* bias, int64_t N,
+                                   const int64_t* row_seg_ptr, const int32_t* seg_row, const int64_t* seg_begin,
+                                   const int64_t* seg_end, int64_t S, const int32_t* order, int64_t n_order,
+                                   int single_segment_rows, const float* Wt, int64_t ldwt, const float* bias, int64_t N,
                                    int act, float lo, float hi, float* C, int64_t ldc, void* ws, size_t ws_bytes, void* stream)
 {
     RECO_REQUIRE(act >= RECO_ACT_NONE && act <= RECO_ACT_RATING, "csr_linear: unknown activation %d", act);
-    return launch_csr_linear(row_ptr, col, val, M, K, row_seg_ptr, seg_row, seg_begin, S, seg_len, Wt, ldwt, bias, N, act, lo, hi,
-                             C, ldc, ws, ws_bytes, (hipStream_t)stream);
+    return launch_csr_linear(row_ptr, col, val, M, K, row_seg_ptr, seg_row, seg_begin, seg_end, S, order, n_order,
+                             single_segment_rows, Wt, ldwt, bias, N, act, lo, hi, C, ldc, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int reco_transpose_f32(const float* in, int64_t rows, int64_t cols, int64_t ld_in, float* out, int64_t ld_out, void* stream)

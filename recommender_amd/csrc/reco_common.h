@@ -82,7 +82,8 @@ size_t topk_workspace_bytes(int64_t rows, int64_t N, int k);
 
 // sparse.hip
 int launch_csr_linear(const int64_t* row_ptr, const int32_t* col, const float* val, int64_t M, int64_t K,
-                      const int64_t* row_seg_ptr, const int32_t* seg_row, const int64_t* seg_begin, int64_t S, int seg_len,
+                      const int64_t* row_seg_ptr, const int32_t* seg_row, const int64_t* seg_begin, const int64_t* seg_end,
+                      int64_t S, const int32_t* order, int64_t n_order, int single_segment_rows,
                       const float* Wt, int64_t ldwt, const float* bias, int64_t N, int act, float lo, float hi,
                       float* C, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t s);
 size_t csr_linear_workspace_bytes(int64_t S, int64_t N);

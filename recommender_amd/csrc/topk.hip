@@ -255,23 +255,57 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(TopkArgs a)
     // 0.354 -> 0.383 ms and per 64-element offer 0.354 -> 0.353 ms on 256 x 1M, k = 100: the key build is not what bounds the scan.)
     if constexpr (VEC == 4) {
         constexpr int UN = RECO_TOPK_UN;
-        auto load = [&](int64_t base, f32x4* v) {
+        // the masks travel with the scores: mk > 0 marks an excluded element.  (Read where they are applied -- after the scores
+        // have arrived -- the mask loads were an exposed round trip per block: 6,040 x 3,706 with the float rating matrix as
+        // the mask took 0.080 ms against 0.040 ms without a mask.)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const bool sf2 = sf && a.ld_seen % 2 == 0 && (uintptr_t)a.seen % 8 == 0;      // rows 8-byte aligned: two float2 per 4 elements
+        const bool ex4 = ex && a.ld_ex % 4 == 0 && (uintptr_t)a.exclude % 4 == 0;      // rows 4-byte aligned: one dword per 4 elements
+        auto load = [&](int64_t base, f32x4* v, f32x4* mk) {
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
                 const int64_t n0 = base + u * 256 + 4 * lane;
                 v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (n0 + 3 < s1) v[u] = *reinterpret_cast<const f32x4*>(src + n0);
+                const bool whole = n0 + 3 < s1;
+                if (whole) v[u] = *reinterpret_cast<const f32x4*>(src + n0);
                 else {
                     if (n0 + 0 < s1) v[u].x = src[n0 + 0];
                     if (n0 + 1 < s1) v[u].y = src[n0 + 1];
                     if (n0 + 2 < s1) v[u].z = src[n0 + 2];
                 }
+                if (!masked) continue;
+                f32x4 m = {0.f, 0.f, 0.f, 0.f};
+                if (sf) {
+                    if (sf2 && whole) {
+                        const f32x2 lo = *reinterpret_cast<const f32x2*>(sf + n0), hi = *reinterpret_cast<const f32x2*>(sf + n0 + 2);
+                        m = f32x4{lo.x, lo.y, hi.x, hi.y};
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (n0 + t < s1) m[t] = sf[n0 + t];
+                    }
+                }
+                if (ex) {
+                    if (ex4 && whole) {
+                        const uint32_t b = *reinterpret_cast<const uint32_t*>(ex + n0);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if ((b >> (8 * t)) & 0xffu) m[t] = 1.f;
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (n0 + t < s1 && ex[n0 + t]) m[t] = 1.f;
+                    }
+                }
+                mk[u] = m;
             }
         };
-        f32x4 v[UN], vn[UN];
-        load(s0, v);
+        f32x4 v[UN], vn[UN], mk[UN], mkn[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) mk[u] = mkn[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        load(s0, v, mk);
         for (int64_t base = s0; base < s1; base += 256 * UN) {
-            if (base + 256 * UN < s1) load(base + 256 * UN, vn);       // next iteration's loads fly under this one's compares
+            if (base + 256 * UN < s1) load(base + 256 * UN, vn, mkn);  // next iteration's loads fly under this one's compares
 #pragma unroll
             for (int u = 0; u < UN; ++u)
 #pragma unroll
@@ -279,12 +313,12 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(TopkArgs a)
                     const int64_t n = base + u * 256 + 4 * lane + t;
                     const bool ok = n < s1;
                     float x = v[u][t];
-                    if (masked && ok && ((ex && ex[n]) || (sf && sf[n] > 0.f))) x = x * 0.f - 1e10f;   // helper.py:313
+                    if (masked && mk[u][t] > 0.f) x = x * 0.f - 1e10f;   // helper.py:313: pred*(~seen) - seen*1e10
                     const u64 key = ((u64)float_key(x) << 32) | (uint32_t)~(uint32_t)n;
                     offer<SLOTS>(L, P, key, ok, thr, a.k, lane);
                 }
 #pragma unroll
-            for (int u = 0; u < UN; ++u) v[u] = vn[u];
+            for (int u = 0; u < UN; ++u) { v[u] = vn[u]; mk[u] = mkn[u]; }
         }
     } else {
         for (int64_t base = s0; base < s1; base += 256) {

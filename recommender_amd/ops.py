@@ -155,10 +155,16 @@ class CsrMatrix:
 
     Built once per rating matrix (start-up work, like packing weights), from a dense tensor or from (row, col, value)
     triplets; the scoring path then never touches the zeros.  `shape` = (rows, cols).
+
+    Segment table (include/reco_hip.h, reco_csr_linear_f32): the columns are cut into `k_ranges` ranges that hold equal shares
+    of the nonzeros; a segment is at most SEG_LEN consecutive nonzeros of one row inside one range; `order` places segment
+    lists so that workgroup b works in range b % k_ranges (one eighth of the weight matrix per XCD on MI355X).
     """
     SEG_LEN = 256
+    K_RANGES = 8
+    SEGS_PER_WG = 4          # RECO_CSR_SEGS_PER_WG
 
-    def __init__(self, row_ptr, col, val, shape):
+    def __init__(self, row_ptr, col, val, shape, k_ranges=None):
         dev = val.device
         if not val.is_cuda:
             raise ValueError("CsrMatrix lives on the GPU")
@@ -170,21 +176,54 @@ class CsrMatrix:
             raise ValueError("CsrMatrix: row_ptr has %d entries for %d rows; col / val have %d / %d entries"
                              % (self.row_ptr.numel(), self.shape[0], self.col.numel(), self.val.numel()))
         self.nnz = int(self.val.numel())
-        # segment table: row r owns max(1, ceil(nnz_r / SEG_LEN)) segments
-        cnt = self.row_ptr[1:] - self.row_ptr[:-1]
-        segs = torch.clamp((cnt + self.SEG_LEN - 1) // self.SEG_LEN, min=1)
-        self.row_seg_ptr = torch.zeros(self.shape[0] + 1, dtype=torch.int64, device=dev)
-        self.row_seg_ptr[1:] = torch.cumsum(segs, 0)
-        rows = torch.arange(self.shape[0], device=dev, dtype=torch.int64)
-        seg_row = torch.repeat_interleave(rows, segs)
-        self.n_seg = int(seg_row.numel())
-        within = torch.arange(self.n_seg, device=dev, dtype=torch.int64) - self.row_seg_ptr[seg_row]
-        self.seg_begin = (self.row_ptr[seg_row] + within * self.SEG_LEN).contiguous()
-        self.seg_row = seg_row.to(torch.int32).contiguous()
         self.device = dev
+        self.k_ranges = int(self.K_RANGES if k_ranges is None else k_ranges)
+        self._build_segments()
+
+    def _build_segments(self):
+        dev, (M, K), R, SEG = self.device, self.shape, max(1, self.k_ranges), self.SEG_LEN
+        i64 = dict(dtype=torch.int64, device=dev)
+        cnt = self.row_ptr[1:] - self.row_ptr[:-1]
+        col = self.col.long()
+        if R > 1 and self.nnz > 0:                      # k ranges with equal shares of the nonzeros
+            cum = torch.cumsum(torch.bincount(col.clamp(0, K - 1), minlength=K), 0)
+            targets = (torch.arange(1, R, **i64) * self.nnz) // R
+            bounds = torch.searchsorted(cum, targets) + 1                  # range r = [bounds[r-1], bounds[r])
+            rng = torch.bucketize(col, bounds, right=True)
+        else:
+            R = 1
+            rng = torch.zeros(self.nnz, **i64)
+        nz_row = torch.repeat_interleave(torch.arange(M, **i64), cnt)
+        gcnt = torch.bincount(nz_row * R + rng, minlength=M * R)           # nonzeros per (row, range); contiguous in CSR order
+        gstart = torch.cumsum(gcnt, 0) - gcnt
+        gsegs = (gcnt + SEG - 1) // SEG                                    # no segment for an empty (row, range)
+        gfirst = torch.cumsum(gsegs, 0) - gsegs
+        self.n_seg = int(gsegs.sum())
+        group = torch.repeat_interleave(torch.arange(M * R, **i64), gsegs)
+        within = torch.arange(self.n_seg, **i64) - gfirst[group]
+        self.seg_begin = (gstart[group] + within * SEG).contiguous()
+        self.seg_end = torch.minimum(self.seg_begin + SEG, gstart[group] + gcnt[group]).contiguous()
+        self.seg_row = (group // R).to(torch.int32).contiguous()
+        seg_rng = group % R
+        row_segs = gsegs.view(M, R).sum(1)
+        self.row_seg_ptr = torch.zeros(M + 1, **i64)
+        self.row_seg_ptr[1:] = torch.cumsum(row_segs, 0)
+        self.single_segment_rows = bool(M > 0 and int((row_segs == 1).all()))
+        self.order = None
+        if R > 1 and self.n_seg > 0:
+            # placement table: SPW slots per workgroup; the i-th segment of range r goes to workgroup (i // SPW) * R + r
+            SPW = self.SEGS_PER_WG
+            per = torch.bincount(seg_rng, minlength=R)
+            by_range = torch.argsort(seg_rng, stable=True)
+            r = seg_rng[by_range]
+            pos = torch.arange(self.n_seg, **i64) - (torch.cumsum(per, 0) - per)[r]
+            groups = (int(per.max()) + SPW - 1) // SPW
+            order = torch.full((groups * R * SPW,), -1, dtype=torch.int32, device=dev)
+            order[((pos // SPW) * R + r) * SPW + pos % SPW] = by_range.to(torch.int32)
+            self.order = order.contiguous()
 
     @classmethod
-    def from_dense(cls, m, transpose=False):
+    def from_dense(cls, m, transpose=False, k_ranges=None):
         """CSR of m (or of m.T) for a dense [rows, cols] device tensor; entries != 0 are kept."""
         m = _f32(m, "matrix", 2)
         v = m.t() if transpose else m
@@ -192,7 +231,7 @@ class CsrMatrix:
         counts = torch.bincount(idx[:, 0], minlength=v.shape[0])
         row_ptr = torch.zeros(v.shape[0] + 1, dtype=torch.int64, device=m.device)
         row_ptr[1:] = torch.cumsum(counts, 0)
-        return cls(row_ptr, idx[:, 1], v[idx[:, 0], idx[:, 1]], v.shape)
+        return cls(row_ptr, idx[:, 1], v[idx[:, 0], idx[:, 1]], v.shape, k_ranges)
 
     @classmethod
     def from_triplets(cls, rows, cols, vals, shape, device):
@@ -229,11 +268,12 @@ def csr_linear(x, weight_t, bias=None, act=None, lo=0.0, hi=0.0, out=None):
     else:
         _check_out(out, (M, N), torch.float32, x.device, "out", rows_may_be_strided=True)
     L = _lib.lib()
-    nbytes = L.reco_csr_linear_workspace_bytes(x.n_seg, N) if x.n_seg > M else 0
+    nbytes = 0 if x.single_segment_rows else L.reco_csr_linear_workspace_bytes(x.n_seg, N)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
     with torch.cuda.device(x.device):
         check(L.reco_csr_linear_f32(_p(x.row_ptr), _p(x.col), _p(x.val), M, K, _p(x.row_seg_ptr), _p(x.seg_row), _p(x.seg_begin),
-                                    x.n_seg, CsrMatrix.SEG_LEN, _p(weight_t), N, _p(bias), N, ACTS[act], lo, hi,
+                                    _p(x.seg_end), x.n_seg, _p(x.order), 0 if x.order is None else x.order.numel(),
+                                    1 if x.single_segment_rows else 0, _p(weight_t), N, _p(bias), N, ACTS[act], lo, hi,
                                     _p(out), out.stride(0) if M > 1 else N, _p(ws), nbytes, _stream(x.device)))
     return out
 

@@ -277,21 +277,29 @@ def test_sparse_linear_over_csr_input(tower_precision):
         Xd = torch.from_numpy(X).cuda(); Wd = torch.from_numpy(W).cuda(); bd = torch.from_numpy(b).cuda()
         csr = ops.CsrMatrix.from_dense(Xd)
         assert csr.nnz == int((X != 0).sum()) and torch.equal(csr.to_dense(), Xd)
+        flat = ops.CsrMatrix.from_dense(Xd, k_ranges=1)      # no k ranges: whole rows, cut only at 256 nonzeros
         if dens > 0 and K > ops.CsrMatrix.SEG_LEN:
-            assert csr.n_seg > M                             # the full row was cut into segments
+            assert flat.n_seg > int((X != 0).any(1).sum())   # the full row was cut into segments (an empty row owns none)
+        if dens > 0:
+            assert csr.order is not None and csr.n_seg >= flat.n_seg
+            o = csr.order.cpu().numpy()
+            assert sorted(o[o >= 0].tolist()) == list(range(csr.n_seg))       # every segment placed exactly once
         Wt = ops.transpose(Wd)
         assert torch.equal(Wt, Wd.t().contiguous())
         got = ops.csr_linear(csr, Wt, bd, act).cpu().numpy()
+        got_flat = ops.csr_linear(flat, Wt, bd, act).cpu().numpy()
         pre64 = X.astype(np.float64) @ W.astype(np.float64).T + b
         ref64 = {"sigmoid": lambda v: 1 / (1 + np.exp(-v)), "relu": lambda v: np.maximum(v, 0), None: lambda v: v}[act](pre64)
         # gate: 1e-5 relative + 1e-6 absolute, plus what ANY fp32 summation of that many terms is entitled to: a few ulps of the
         # sum of the terms' magnitudes (the fully observed 6,040-entry row sums ~190 in magnitude to reach values of ~0.04; all
         # three activations are 1-Lipschitz, so the bound carries over)
         slack = 2e-7 * (np.abs(X).astype(np.float64) @ np.abs(W).astype(np.float64).T + np.abs(b))
-        for name, other in (("fp64", ref64), ("the dense MFMA layer", ops.linear(Xd, Wd, bd, act, precision="f32").cpu().numpy())):
-            err = np.abs(got - other)
-            tol = 1e-5 * np.maximum(np.abs(got), np.abs(other)) + 1e-6 + slack
-            assert (err <= tol).all(), "csr_linear vs %s (%d,%d,%d): worst err/tol %.2f" % (name, M, K, N, (err / tol).max())
+        dense_out = ops.linear(Xd, Wd, bd, act, precision="f32").cpu().numpy()
+        for mine in (got, got_flat):
+            for name, other in (("fp64", ref64), ("the dense MFMA layer", dense_out)):
+                err = np.abs(mine - other)
+                tol = 1e-5 * np.maximum(np.abs(mine), np.abs(other)) + 1e-6 + slack
+                assert (err <= tol).all(), "csr_linear vs %s (%d,%d,%d): worst err/tol %.2f" % (name, M, K, N, (err / tol).max())
         sparse_rows = (X != 0).sum(1) < 400                         # rows like the real matrix's: the plain gate, no slack
         if sparse_rows.any():
             assert_close(got[sparse_rows], ref64[sparse_rows], atol=2e-6, what="csr_linear, sparse rows vs fp64")
