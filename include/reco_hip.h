@@ -218,6 +218,20 @@ int reco_tower_score_topk(reco_tower_t* t, const int64_t* users, int64_t user_ba
                           int32_t* out_ids, float* out_scores, int32_t* oob,
                           void* ws, size_t ws_bytes, void* stream);
 
+/* The same selection with NO score rows in memory: one kernel scores and keeps every user's running top-k in registers
+ * (tower_tile_topk_kernel), a second folds the few partial lists per user.  Mask-free calls on the exact MFMA tower only
+ * (a GMF-only or split-mode handle returns RECO_EINVAL); results are bit-identical to reco_tower_score_topk.
+ * replaces the same reference lines (inference_engine.py:162-166; SURVEY section 7 "the score row never reaches HBM").
+ * Trade (measured): HBM writes per launch fall from the score rows (85 MB at 6038 x 3533) to the lists,
+ * the workspace from U x N floats to U x ~4 lists, the time RISES by 1-3 % (the list upkeep shares the SIMDs with the
+ * MFMAs), and a request for a handful of users over a long catalog is slower still -- hence a separate entry point, not the
+ * default.  The workspace size depends on the handle (its user-block size). */
+size_t reco_tower_topk_fused_workspace_bytes(const reco_tower_t* t, int64_t U, int64_t N, int k);
+int reco_tower_score_topk_fused(reco_tower_t* t, const int64_t* users, int64_t user_base, int64_t U,
+                                const int64_t* cands, int64_t N, int k,
+                                int32_t* out_ids, float* out_scores, int32_t* oob,
+                                void* ws, size_t ws_bytes, void* stream);
+
 /* score_matrix / score_topk over row blocks handed in per call: out[u, n] = score(row u of the user blocks, row n of the item
  * blocks) for all U x N combinations -- the Hybrid model's full-catalog evaluation, where the "tables" are this call's encoder
  * latents (replaces the O(blocks x items) full-model loop of hybridautorecncf.ipynb cell 13 around

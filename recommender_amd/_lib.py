@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("RECO_HIP_LIB") or os.path.join(_HERE, "lib", "libreco
 OK, EINVAL, EHIP, ENOMEM, EINDEX = 0, -1, -2, -3, -4
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_CLAMP, ACT_RATING = 0, 1, 2, 3, 4
 PREC_F32, PREC_SPLIT_BF16X3 = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class TowerDesc(Structure):
@@ -65,6 +65,9 @@ _SIGNATURES = {
     "reco_tower_score_topk_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
                                            c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "reco_noalloc_scratch_bytes": (c_size_t, []),
+    "reco_tower_topk_fused_workspace_bytes": (c_size_t, [c_void_p, c_int64, c_int64, c_int]),
+    "reco_tower_score_topk_fused": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int,
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "reco_tower_score_topk_noalloc": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int,
                                               c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "reco_topk_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),

@@ -32,6 +32,13 @@ int tower_launch_pairs_split(int G, int has_l3, const void* img, const float* P,
                              const float* EUg, const float* EIg, const int64_t* user, const int64_t* item,
                              int64_t n_users, int64_t n_items, int64_t B, float* out, float bp, int act,
                              float lo, float hi, int32_t* oob, hipStream_t s);
+int tower_tile_users_per_block(int G);
+size_t tower_topk_counter_bytes(int G, int64_t U);
+int tower_launch_tile_topk(int G, int has_l3, const float* img, const float* P, const float* Q,
+                           const float* EUg, const float* EIg, const int64_t* users, const int64_t* cands,
+                           int64_t user_base, int64_t n_users, int64_t n_items, int64_t U, int64_t N,
+                           float bp, int act, float lo, float hi, int32_t* oob,
+                           int k, int v_max, unsigned int* counters, unsigned long long* partial, hipStream_t s);
 int gmf_launch_pairs(const float* EUg, const float* EIg, const float* wp, const int64_t* user,
                      const int64_t* item, int64_t n_users, int64_t n_items, int64_t B, int G, float* out,
                      float bp, int act, float lo, float hi, int32_t* oob, hipStream_t s);
@@ -54,7 +61,7 @@ void reco_set_error(const char* fmt, ...)
 }
 
 extern "C" const char* reco_last_error(void) { return g_err; }
-extern "C" int reco_abi_version(void) { return 3; }
+extern "C" int reco_abi_version(void) { return 4; }
 
 // ---------------------------------------------------------------------------------------------
 // measurement hook: hipEvent pairs around the dominant kernel's launches
@@ -469,10 +476,91 @@ static size_t topk_chunk_bytes(int64_t Uc, int64_t N, int k)
            align_up((size_t)(Uc + kTopkExtraRows) * k * sizeof(uint64_t), 256);
 }
 
+// ---- fused form: tower_tile_topk_kernel keeps every user's running top-k in registers, the score rows never reach HBM ----
+// Partial lists ("visitor slots", tower.hip) per user block: a workgroup that joins a block takes one, so few blocks (a request
+// for a handful of users over a long catalog: ONE block for all 256 CUs) need many, many blocks need few.  About three visits
+// per CU over a launch: 1024 users x 1M items (43 blocks) with 8 slots left two blocks short of helpers at the end (+11 %).
+// A workgroup visits a block at most once, so one slot per CU is always enough.
+static const int kFuseVisitorsMin = 4, kFuseVisitorsMax = 256;
+static const size_t kFusePartialBytes = (size_t)256 << 20;   // user chunks are sized so that the partial lists stay below this
+
+static int fuse_visitors(int G, int64_t Uc)
+{
+    const int64_t blocks = (Uc + tower_tile_users_per_block(G) - 1) / tower_tile_users_per_block(G);
+    int64_t v = (3 * 256 + blocks - 1) / (blocks > 0 ? blocks : 1);
+    return (int)(v < kFuseVisitorsMin ? kFuseVisitorsMin : (v > kFuseVisitorsMax ? kFuseVisitorsMax : v));
+}
+
+static size_t fused_partial_bytes(int64_t Uc, int v, int k) { return align_up((size_t)Uc * v * k * sizeof(uint64_t), 256); }
+
+static size_t fused_chunk_bytes(int G, int64_t Uc, int64_t N, int k)
+{
+    return kQueueBytes + proj_bytes(N) + proj_bytes(Uc) + tower_topk_counter_bytes(G, Uc) + fused_partial_bytes(Uc, fuse_visitors(G, Uc), k);
+}
+
+static int64_t fused_default_chunk(int64_t U, int k)
+{
+    // large chunks run at the minimum list count; small ones hold <= ~768 lists per 24 users, 19 MB at k = 128
+    int64_t c = (int64_t)(kFusePartialBytes / ((size_t)kFuseVisitorsMin * k * sizeof(uint64_t)));
+    if (c < 32) c = 32;
+    return c < U ? c : U;
+}
+
+// Only the exact MFMA tower has the fused kernel (GMF-only models and the split mode keep score rows in the workspace).
+static bool fused_topk_available(const reco_tower* t) { return t->mfma && !t->img_split; }
+
 extern "C" size_t reco_tower_topk_workspace_bytes(int64_t U, int64_t N, int k)
 {
     if (U <= 0 || N <= 0 || k <= 0) return 0;
     return topk_chunk_bytes(default_chunk(U, N), N, k);
+}
+
+extern "C" size_t reco_tower_topk_fused_workspace_bytes(const reco_tower_t* t, int64_t U, int64_t N, int k)
+{
+    if (!t || !fused_topk_available(t) || U <= 0 || N <= 0 || k <= 0) return 0;
+    return fused_chunk_bytes(t->G, fused_default_chunk(U, k), N, k);
+}
+
+static int score_topk_fused(reco_tower_t* t, const int64_t* users, int64_t user_base, int64_t U, const int64_t* cands, int64_t N,
+                            int k, int32_t* out_ids, float* out_scores, int32_t* oob, void* ws, size_t ws_bytes, hipStream_t s,
+                            const char* who)
+{
+    const reco_tower_desc_t& d = t->d;
+    int64_t Uc = fused_default_chunk(U, k);
+    while (Uc > 1 && fused_chunk_bytes(t->G, Uc, N, k) > ws_bytes) Uc = Uc / 2;
+    if (!ws || fused_chunk_bytes(t->G, Uc, N, k) > ws_bytes) {
+        reco_set_error("%s: workspace too small (%zu bytes; one user needs %zu)", who, ws_bytes, fused_chunk_bytes(t->G, 1, N, k));
+        return RECO_ENOMEM;
+    }
+    char* w = static_cast<char*>(ws) + kQueueBytes;
+    float* Q = reinterpret_cast<float*>(w); w += proj_bytes(N);
+    float* P = reinterpret_cast<float*>(w); w += proj_bytes(Uc);
+    unsigned int* counters = reinterpret_cast<unsigned int*>(w);
+    const size_t counter_bytes = tower_topk_counter_bytes(t->G, Uc);       // whole chunks and the last, shorter one share this split
+    const int64_t list_room = Uc * fuse_visitors(t->G, Uc);                // partial lists the workspace was sized for
+    unsigned long long* partial = reinterpret_cast<unsigned long long*>(w + counter_bytes);
+    const bool cached_q = !cands && N == d.n_items && U <= kServingUsers && t->Q;     // as the unfused form below
+    int rc = RECO_OK;
+    if (cached_q) Q = t->Q;
+    else if ((rc = tower_project(t, nullptr, nullptr, 0, 0, d.item_mlp, cands, d.n_items, N, nullptr, Q, oob, s))) return rc;
+    for (int64_t c0 = 0; c0 < U; c0 += Uc) {
+        const int64_t n = U - c0 < Uc ? U - c0 : Uc;
+        const int64_t* ul = users ? users + c0 : nullptr;
+        const float* urows = ul ? d.user_mlp : d.user_mlp + (user_base + c0) * d.dm;
+        if ((rc = tower_project(t, urows, ul, d.n_users, n, nullptr, nullptr, 0, 0, P, nullptr, oob, s))) return rc;
+        // hand-out counters and partial lists start at zero (a list nobody wrote reads as empty)
+        int v = fuse_visitors(t->G, n);                                    // a short last chunk may take more lists per block
+        if ((int64_t)v * n > list_room) v = (int)(list_room / n);
+        RECO_CHECK_HIP(hipMemsetAsync(counters, 0, counter_bytes + fused_partial_bytes(n, v, k), s));
+        {
+            ProfScope prof(s);
+            rc = tower_launch_tile_topk(t->G, t->has_l3, t->img, P, Q, d.user_gmf, d.item_gmf, ul, cands, user_base + c0, d.n_users,
+                                        d.n_items, n, N, t->bp, d.act, d.lo, d.hi, oob, k, v, counters, partial, s);
+        }
+        if (rc) return rc;
+        if ((rc = launch_topk_merge(partial, n, v, k, out_ids + c0 * k, out_scores + c0 * k, s))) return rc;
+    }
+    return RECO_OK;
 }
 
 static int score_topk_impl(reco_tower_t* t, const int64_t* users, int64_t user_base, int64_t U,
@@ -521,6 +609,23 @@ static int score_topk_impl(reco_tower_t* t, const int64_t* users, int64_t user_b
         if (rc) return rc;
     }
     return RECO_OK;
+}
+
+extern "C" int reco_tower_score_topk_fused(reco_tower_t* t, const int64_t* users, int64_t user_base, int64_t U,
+                                           const int64_t* cands, int64_t N, int k, int32_t* out_ids, float* out_scores,
+                                           int32_t* oob, void* ws, size_t ws_bytes, void* stream)
+{
+    RECO_REQUIRE(t, "score_topk_fused: null handle");
+    if (int rc_dev = check_device(t, "score_topk_fused")) return rc_dev;
+    RECO_REQUIRE(fused_topk_available(t), "score_topk_fused: only the exact MFMA tower has the fused kernel (this handle is %s); "
+                 "use reco_tower_score_topk", t->mfma ? "in split bf16x3 mode" : "GMF-only");
+    if (U <= 0) return RECO_OK;
+    const char* who = "score_topk_fused";
+    RECO_REQUIRE(out_ids && out_scores, "%s: null output", who);
+    RECO_REQUIRE(k >= 1 && k <= 128, "%s: k must be in [1,128], got %d", who, k);
+    RECO_REQUIRE(N >= k, "%s: k=%d exceeds the number of candidates %lld", who, k, (long long)N);
+    if (int rc = check_ranges(t, users, user_base, U, cands, N, who)) return rc;
+    return score_topk_fused(t, users, user_base, U, cands, N, k, out_ids, out_scores, oob, ws, ws_bytes, (hipStream_t)stream, who);
 }
 
 extern "C" int reco_tower_score_topk(reco_tower_t* t, const int64_t* users, int64_t user_base, int64_t U,

@@ -79,6 +79,7 @@ int launch_topk_rows_ex(const float* scores, int64_t rows, int64_t N, int64_t ld
                         const int64_t* row_ids, int64_t src_rows, int32_t* oob, int32_t* out_ids, float* out_vals,
                         void* ws, size_t ws_bytes, hipStream_t s);
 size_t topk_workspace_bytes(int64_t rows, int64_t N, int k);
+int launch_topk_merge(const unsigned long long* partial, int64_t rows, int splits, int k, int32_t* out_ids, float* out_vals, hipStream_t s);
 
 // sparse.hip
 int launch_csr_linear(const int64_t* row_ptr, const int32_t* col, const float* val, int64_t M, int64_t K,

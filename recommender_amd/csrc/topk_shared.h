@@ -1,0 +1,188 @@
+// Wave-level top-k primitives shared by the stand-alone select (topk.hip) and the fused score + select tile kernel
+// (tower.hip): order-preserving keys, the sorted register-resident list, batched entrants.  See topk.hip for the scheme.
+#pragma once
+#include "reco_common.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ uint32_t float_key(float v)
+{
+    if (v != v) return 0xFFFFFFFFu;          // NaN ranks first (numpy sorts NaN last ascending; torch.topk: largest)
+    v += 0.f;                                // -0.0 -> +0.0 so that equal scores have equal keys
+    const uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ float key_float(uint32_t k)
+{
+    if (k == 0xFFFFFFFFu) return __uint_as_float(0x7FC00000u);
+    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+
+__device__ __forceinline__ u64 shfl_up1(u64 v, int lane)
+{
+    const int src = lane > 0 ? lane - 1 : 0;
+    const uint32_t lo = __shfl((uint32_t)v, src);
+    const uint32_t hi = __shfl((uint32_t)(v >> 32), src);
+    return ((u64)hi << 32) | lo;
+}
+
+__device__ __forceinline__ u64 bcast(u64 v, int src)
+{
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src);
+    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src);
+    return ((u64)hi << 32) | lo;
+}
+
+__device__ __forceinline__ u64 shfl_xor64(u64 v, int mask)
+{
+    const uint32_t lo = __shfl_xor((uint32_t)v, mask);
+    const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), mask);
+    return ((u64)hi << 32) | lo;
+}
+
+// one compare-exchange stage of a descending bitonic network: the lower lane of each pair keeps the larger key
+__device__ __forceinline__ u64 cmpx_desc(u64 v, int j, int lane, bool descending)
+{
+    const u64 o = shfl_xor64(v, j);
+    const bool lower = (lane & j) == 0;
+    return (lower == descending) ? (v > o ? v : o) : (v < o ? v : o);
+}
+
+// bitonic sort of one key per lane, descending across the wave (21 stages)
+__device__ __forceinline__ u64 wave_sort_desc(u64 v, int lane)
+{
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) v = cmpx_desc(v, j, lane, (lane & k) == 0);
+    return v;
+}
+
+// Sorted (descending) list of 64 * SLOTS keys across the wave.  0 = empty.
+template <int SLOTS>
+struct WaveList {
+    u64 e[SLOTS];
+    __device__ __forceinline__ void clear()
+    {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) e[s] = 0;
+    }
+    // x is wave-uniform
+    __device__ __forceinline__ void insert(u64 x, int lane)
+    {
+        u64 carry = x;   // element entering slot s (at position pos, or at lane 0 when carried over)
+        bool placed = false;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            if (!placed) {
+                const int pos = __popcll(__ballot(e[s] > x));   // e[s] sorted descending: prefix of greater keys
+                if (pos < 64) {
+                    const u64 up = shfl_up1(e[s], lane);
+                    const u64 last = bcast(e[s], 63);
+                    e[s] = lane < pos ? e[s] : (lane == pos ? x : up);
+                    carry = last;
+                    placed = true;
+                }
+            } else {
+                const u64 up = shfl_up1(e[s], lane);
+                const u64 last = bcast(e[s], 63);
+                e[s] = lane == 0 ? carry : up;
+                carry = last;
+            }
+        }
+    }
+    // c: 64 keys sorted descending across the lanes.  The list becomes the best 64 * SLOTS of (list U c):
+    // max(list[r], c_padded[last - r]) holds that set as a bitonic sequence, log2 merge stages sort it.
+    __device__ __forceinline__ void merge_sorted(u64 c, int lane)
+    {
+        const int src = 63 - lane;
+        const uint32_t lo = __shfl((uint32_t)c, src), hi = __shfl((uint32_t)(c >> 32), src);
+        const u64 r = ((u64)hi << 32) | lo;
+        e[SLOTS - 1] = e[SLOTS - 1] > r ? e[SLOTS - 1] : r;
+        if (SLOTS == 2) {
+            const u64 a = e[0], b = e[SLOTS - 1];
+            e[0] = a > b ? a : b;
+            e[SLOTS - 1] = a > b ? b : a;
+        }
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+#pragma unroll
+            for (int j = 32; j > 0; j >>= 1) e[s] = cmpx_desc(e[s], j, lane, true);
+    }
+    __device__ __forceinline__ u64 kth(int k) const   // key at rank k-1 (wave-uniform)
+    {
+        u64 r = 0;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+            if (((k - 1) >> 6) == s) r = bcast(e[s], (k - 1) & 63);
+        return r;
+    }
+};
+
+// Candidates are not inserted as they appear: keys that beat the current k-th key are compacted into a per-wave PENDING
+// register (lane r = r-th pending key, ds_permute push) and only when 64 are pending -- or the row segment ends -- are they
+// bitonic-sorted across the wave and merged with the list as two sorted sequences (27-28 shuffle stages whatever the count;
+// a handful of keys are inserted serially instead).  A serial insert costs ~40 instructions per key and slot; batched, an
+// entrant costs ~5.  The threshold is the k-th key as of the last flush, so a few more keys than strictly necessary are
+// collected; the merge drops them.
+constexpr int SERIAL_INSERTS_MAX = 4;
+
+__device__ __forceinline__ u64 permute_push64(u64 v, int dst_lane)      // lane dst_lane receives v (a bijection of lanes)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_permute(dst_lane << 2, (int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_permute(dst_lane << 2, (int)(uint32_t)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+
+struct Pending {
+    u64 key;     // lanes [0, n) hold pending keys, the others 0
+    int n;       // wave-uniform
+    __device__ __forceinline__ void clear() { key = 0; n = 0; }
+};
+
+template <int SLOTS>
+__device__ __forceinline__ void flush(WaveList<SLOTS>& L, Pending& P, u64& thr, int k, int lane)
+{
+    if (P.n == 0) return;
+    if (P.n <= SERIAL_INSERTS_MAX) {
+        for (int i = 0; i < P.n; ++i) {
+            const u64 x = bcast(P.key, i);
+            if (x > thr) {               // thr may have risen since the key was collected
+                L.insert(x, lane);
+                thr = L.kth(k);
+            }
+        }
+    } else {
+        L.merge_sorted(wave_sort_desc(P.key, lane), lane);
+        thr = L.kth(k);
+    }
+    P.clear();
+}
+
+template <int SLOTS>
+__device__ __forceinline__ void offer(WaveList<SLOTS>& L, Pending& P, u64 key, bool valid, u64& thr, int k, int lane)
+{
+    bool cand = valid && key > thr;
+    u64 m = __ballot(cand);
+    int c = __popcll(m);
+    if (c == 0) return;
+    if (P.n + c > 64) {
+        flush<SLOTS>(L, P, thr, k, lane);
+        cand = cand && key > thr;
+        m = __ballot(cand);
+        c = __popcll(m);
+        if (c == 0) return;
+    }
+    // candidates go to lanes n .. n + c - 1 in lane order; the other lanes push a zero to the remaining lanes (mod 64), so the
+    // permutation is a bijection and no lane is targeted twice
+    const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    const int dst = cand ? P.n + below : ((P.n + c + (lane - below)) & 63);
+    const u64 got = permute_push64(cand ? key : 0, dst);
+    if (lane >= P.n && lane < P.n + c) P.key = got;
+    P.n += c;
+}
+
+}  // namespace

@@ -21,6 +21,7 @@
 //   layer 3, quad q' (0..7), step jj, half h:           k = 32 (q' >> 2) + 8 (q' & 3) + 4 h + jj
 //                                                      (= the feature held by acc[q' >> 2][4 (q' & 3) + jj])
 #include "tower_shared.h"
+#include "topk_shared.h"
 
 namespace {
 
@@ -300,6 +301,272 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused score + per-user top-k: the score rows never reach HBM (north_star (d)).
+// ---------------------------------------------------------------------------------------------
+// Same tile body as tower_tile_kernel, different hand-out and a different sink.  A wave owns users w, w + WAVES of a user block and
+// keeps, per user, the best k scores so far SORTED IN REGISTERS (topk_shared.h: 64-bit keys, entrants batched 64 at a time); the
+// 64 scores of a tile row (two MFMA column groups) are offered to that list as they leave the accumulators.
+// Hand-out: every USER BLOCK has its own counter of item tiles.  A workgroup stays on its block -- its lists stay live -- and
+// pulls that block's item tiles one at a time; when the block runs dry it writes its lists out as one of the block's V partial
+// lists ("visitor slots", claimed by an atomic) and moves on: to a block nobody has started (a global counter), else to a block
+// in progress that still has tiles and a free slot.  Balance is at
+// single-tile granularity (several workgroups can drain one block: cfg5 has 43 user blocks for 256 CUs), while a list is flushed
+// only when a workgroup leaves a block -- once or twice per launch.  A merge launch (topk_merge_kernel) folds the <= V sorted
+// partial lists of every user; slots nobody wrote are zero = empty (the buffer is cleared per launch).
+// Results are bit-identical to score_matrix + reco_topk_rows: the scores are the same and the keys carry the position.
+struct TopkFuse {
+    int k;
+    int v_max;                  // visitor slots (partial lists) per user block, <= 1024
+    unsigned int* fresh;        // [1] user blocks handed out beyond the first gridDim.x, zeroed per launch
+    unsigned int* next_tile;    // [user blocks] item-tile counter, zeroed per launch
+    unsigned int* visits;       // [user blocks] visitor counter, zeroed per launch
+    u64* partial;               // [U][v_max][k], zeroed per launch
+};
+
+template <int G, bool L3, int THREADS, int TUBX, int SLOTS>
+__global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_topk_kernel(TileArgs a, TopkFuse f)
+{
+    constexpr int TILE_THREADS = THREADS;
+    constexpr int TUB = TUBX;
+    constexpr int WAVES = THREADS / 64;
+    constexpr int UPW = TUB / WAVES;                            // users per wave (2)
+    static_assert(UPW == 2 && TI == 64, "the fused sink is written for two users per wave and two column groups per tile");
+    constexpr int GS = G + 4;
+    constexpr int BUF = TI * QS + (G > 0 ? TI * GS : 0);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_img = smem;
+    float* s_buf = smem + IMG_SIZE;
+    constexpr int NP = (TUB * (H1 / 4) + TILE_THREADS - 1) / TILE_THREADS;
+    float* s_pbuf = s_buf + 2 * BUF;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    const unsigned tiles_n = (unsigned)((a.N + TI - 1) / TI);
+    const unsigned blocks_u = (unsigned)((a.U + TUB - 1) / TUB);
+
+    for (int i = tid; i < IMG_SIZE / 4; i += TILE_THREADS)
+        reinterpret_cast<f32x4*>(s_img)[i] = reinterpret_cast<const f32x4*>(a.img)[i];
+
+    // ---- hand-out (wave 0; every value below is wave-uniform): the tile fetched last belongs to (q_blk, q_v) ----
+    constexpr int LIST_SHIFT = 10;                             // published as block << 10 | visitor slot
+    __shared__ unsigned s_blkv[2], s_t[2];                     // published tile: block / slot, item tile (~0u: none)
+    const unsigned v_max = (unsigned)f.v_max;
+    unsigned q_blk = 0, q_v = 0;
+    bool q_have = false;                                       // the workgroup holds a visitor slot in q_blk
+    bool q_started = false, q_done = false;
+    auto one = [&](unsigned* p) -> unsigned {                  // one atomic increment per wave, result in a scalar
+        unsigned r = 0;
+        if (lane == 0) r = atomicAdd(p, 1u);
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+    };
+    auto try_block = [&](unsigned b, unsigned& t) {            // join block b if it has a free partial list and a tile left
+        const unsigned v = one(&f.visits[b]);
+        if (v >= v_max) return false;                          // every partial list of that block is taken
+        const unsigned tt = one(&f.next_tile[b]);
+        if (tt >= tiles_n) return false;                       // drained meanwhile: the claimed list stays empty (zero keys)
+        q_blk = b; q_v = v; q_have = true; t = tt;
+        return true;
+    };
+    // Help with a block in progress.  Optional -- whoever holds a block drains it -- so the search is bounded: the blocks handed
+    // out last are the ones still running at the end.  64 blocks are probed per round trip, one per lane (probed one after the
+    // other by a single thread, 252 drained blocks cost every workgroup ~0.25 ms at the end of a 3.3 ms launch).
+    auto help = [&](unsigned& t) {
+        const unsigned window = blocks_u < 256u ? blocks_u : 256u;
+        for (unsigned base = 0; base < window && !q_have; base += 64) {
+            const unsigned i = base + lane;
+            const unsigned b = blocks_u - 1u - (blockIdx.x + i) % window;
+            bool ok = false;
+            if (i < window)
+                ok = __hip_atomic_load(&f.next_tile[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < tiles_n &&
+                     __hip_atomic_load(&f.visits[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v_max;
+            u64 m = __ballot(ok);
+            while (m != 0 && !q_have) {
+                const int l = __ffsll((unsigned long long)m) - 1;
+                m &= m - 1;
+                try_block((unsigned)__builtin_amdgcn_readlane((int)b, l), t);
+            }
+        }
+    };
+    // Claiming a tile is split in two so that the counter's round trip is never waited for: the atomic is issued at the top of a
+    // tile (fetch_issue) and its result looked at after the tile's MFMAs (fetch).
+    unsigned t_raw = 0;                                        // lane 0
+    auto fetch_issue = [&]() { if (q_have && lane == 0) t_raw = atomicAdd(&f.next_tile[q_blk], 1u); };
+    auto fetch = [&](int slot) {                               // wave 0: publish the next tile in LDS slot `slot`
+        unsigned t = ~0u;
+        if (q_have) {                                          // 1. stay on the block: its lists are live in this workgroup
+            t = (unsigned)__builtin_amdgcn_readfirstlane((int)t_raw);
+            if (t >= tiles_n) { t = ~0u; q_have = false; }
+        }
+        if (!q_have && !q_done) {
+            if (!q_started) {                                  // 2a. the workgroup's own first block
+                q_started = true;
+                if (blockIdx.x < blocks_u) try_block(blockIdx.x, t);
+            }
+            while (!q_have) {                                  // 2b. a block nobody has been handed yet
+                const unsigned b = gridDim.x + one(f.fresh);
+                if (b >= blocks_u) break;
+                try_block(b, t);
+            }
+            if (!q_have) help(t);                              // 3. a block in progress
+            if (!q_have) q_done = true;                        // nothing left that this workgroup could join: stop looking
+        }
+        if (lane == 0) {
+            s_blkv[slot] = (q_blk << LIST_SHIFT) | q_v;
+            s_t[slot] = q_have ? t : ~0u;
+        }
+    };
+
+    f32x4 pst[NP];
+    auto p_stage_load = [&](unsigned blk) {
+        const int64_t ub = (int64_t)blk * TUB;
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+            const int i = tid + s * TILE_THREADS;
+            const int64_t u = ub + (i >> 5);
+            pst[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < TUB * (H1 / 4) && u < a.U) pst[s] = reinterpret_cast<const f32x4*>(a.P + u * H1)[i & 31];
+        }
+    };
+    auto p_stage_store = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < NP; ++s)
+            if (tid + s * TILE_THREADS < TUB * (H1 / 4))
+                reinterpret_cast<f32x4*>(s_pbuf + buf * TUB * H1)[tid + s * TILE_THREADS] = pst[s];
+    };
+
+    // ---- per-wave top-k state: one sorted list per owned user ----
+    WaveList<SLOTS> L0, L1;
+    Pending P0, P1;
+    u64 thr0 = 0, thr1 = 0;
+    L0.clear(); L1.clear(); P0.clear(); P1.clear();
+    unsigned list_blkv = ~0u;                                  // block / slot the lists belong to (~0u: nothing collected yet)
+    auto write_lists = [&]() {                                 // this wave's two users of block list_blkv -> their partial lists
+        const unsigned blk = list_blkv >> LIST_SHIFT, v = list_blkv & ((1u << LIST_SHIFT) - 1u);
+        flush<SLOTS>(L0, P0, thr0, f.k, lane);
+        flush<SLOTS>(L1, P1, thr1, f.k, lane);
+#pragma unroll
+        for (int ui = 0; ui < UPW; ++ui) {
+            const int64_t u = (int64_t)blk * TUB + wave + ui * WAVES;
+            if (u >= a.U) continue;
+            u64* dst = f.partial + (u * f.v_max + v) * f.k;
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const int r = s * 64 + lane;
+                if (r < f.k) dst[r] = ui == 0 ? L0.e[s] : L1.e[s];
+            }
+        }
+        L0.clear(); L1.clear(); P0.clear(); P1.clear();
+        thr0 = 0; thr1 = 0;
+    };
+
+    TileStage<G, THREADS> st;
+    if (wave == 0) { fetch(0); fetch_issue(); fetch(1); }
+    __syncthreads();
+    unsigned cur_blkv = s_blkv[0], cur_t = s_t[0];
+    if (cur_t != ~0u) {
+        tile_stage_load<G, THREADS>(a, (int64_t)cur_t * TI, (cur_blkv >> LIST_SHIFT) == 0, tid, st);
+        tile_stage_store<G, THREADS>(s_buf, s_buf + TI * QS, tid, st);
+        p_stage_load(cur_blkv >> LIST_SHIFT);
+        p_stage_store(0);
+    }
+    __syncthreads();
+    unsigned nxt_blkv = s_blkv[1], nxt_t = s_t[1];
+
+    for (int it = 0; cur_t != ~0u; ++it) {
+        const float* s_q = s_buf + (it & 1) * BUF;
+        const float* s_g = s_q + TI * QS;
+        const int64_t n0 = (int64_t)cur_t * TI;
+        const int64_t u0 = (int64_t)(cur_blkv >> LIST_SHIFT) * TUB;
+        if (wave == 0) fetch_issue();                           // the tile after next: claimed now, published below
+        if (nxt_t != ~0u) { tile_stage_load<G, THREADS>(a, (int64_t)nxt_t * TI, (nxt_blkv >> LIST_SHIFT) == 0, tid, st); p_stage_load(nxt_blkv >> LIST_SHIFT); }
+        const float* s_p = s_pbuf + (it & 1) * TUB * H1;
+        if (cur_blkv != list_blkv) {                           // the workgroup moved to another block (or holds its first tile)
+            if (list_blkv != ~0u) write_lists();
+            list_blkv = cur_blkv;
+        }
+
+        // ONE copy of the tile body for both users of the wave (the loop is not unrolled: two copies of 160 MFMAs plus the list
+        // code were ~56 KB of instructions): the body always works on L0 / P0 / thr0 and the two users' states trade places
+        // after every pass, so after the two passes each is back where it started
+#pragma unroll 1
+        for (int ui = 0; ui < UPW; ++ui) {
+            const int uu = wave + ui * WAVES;
+            const int64_t u = u0 + uu;
+            if (u < a.U) {
+            f32x4 gu[G > 0 ? G / 8 : 1];
+            if constexpr (G > 0) {
+                const int64_t uid = clamp_id(a.users ? a.users[u] : a.user_base + u, a.n_users, (lane == 0 && n0 == 0) ? a.oob : nullptr);
+                const f32x4* gr = reinterpret_cast<const f32x4*>(a.EUg + uid * G + h * (G / 2));
+                const float* wpg = s_img + IMG_WPG + h * (G / 2);
+#pragma unroll
+                for (int c = 0; c < G / 8; ++c) gu[c] = gr[c] * *reinterpret_cast<const f32x4*>(wpg + 4 * c);
+            }
+            float held = 0.f;                                  // group 0's score of pair j, until group 1's is ready
+#pragma unroll 1
+            for (int g = 0; g < TI / 32; ++g) {
+                asm volatile("" ::: "memory");
+                const float* qrow = s_q + (g * 32 + j) * QS + 4 * h;
+                struct PQ { f32x4 q, p; };
+                struct X1TileLds {
+                    const float* qrow;
+                    const float* prow;
+                    __device__ __forceinline__ PQ raw(int q) const
+                    {
+                        return PQ{*reinterpret_cast<const f32x4*>(qrow + 8 * q), *reinterpret_cast<const f32x4*>(prow + 8 * q)};
+                    }
+                    __device__ __forceinline__ void pre(int) const {}
+                    __device__ __forceinline__ f32x4 finish(int, const PQ& v) const { return relu4(v.p + v.q); }
+                    __device__ __forceinline__ f32x4 passthrough(const PQ& v) const { return v.q; }
+                };
+                float part = tower_mlp_part<L3>(s_img, lane, X1TileLds{qrow, s_p + uu * H1 + 4 * h});
+                if constexpr (G > 0) {
+                    const float* grow = s_g + (g * 32 + j) * GS + h * (G / 2);
+#pragma unroll
+                    for (int c = 0; c < G / 8; ++c) {
+                        const f32x4 gi = *reinterpret_cast<const f32x4*>(grow + 4 * c);
+                        part = fmaf(gu[c].x, gi.x, part);
+                        part = fmaf(gu[c].y, gi.y, part);
+                        part = fmaf(gu[c].z, gi.z, part);
+                        part = fmaf(gu[c].w, gi.w, part);
+                    }
+                }
+                const float sc = epilogue(part + __shfl_xor(part, 32) + a.bp, a.act, a.lo, a.hi);
+                if (g == 0) held = sc;
+                else {
+                    // lanes 0..31 offer group 0's scores (items n0 + j), lanes 32..63 group 1's (items n0 + 32 + j): item n0 + lane
+                    const float x = h == 0 ? held : sc;
+                    // one float compare decides the common case (no score of the tile row reaches the k-th key's score; NaN
+                    // on either side passes and is settled by the exact keys)
+                    const float tf = key_float((uint32_t)(thr0 >> 32));
+                    if (__ballot(!(x < tf)) != 0) {
+                        const int64_t n = n0 + lane;
+                        const u64 key = ((u64)float_key(x) << 32) | (uint32_t)~(uint32_t)n;
+                        offer<SLOTS>(L0, P0, key, n < a.N, thr0, f.k, lane);
+                    }
+                }
+            }
+            }
+            { const WaveList<SLOTS> tl = L0; L0 = L1; L1 = tl; }
+            { const Pending tp = P0; P0 = P1; P1 = tp; }
+            { const u64 tt = thr0; thr0 = thr1; thr1 = tt; }
+        }
+        if (nxt_t != ~0u) {
+            float* d_q = s_buf + ((it + 1) & 1) * BUF;
+            tile_stage_store<G, THREADS>(d_q, d_q + TI * QS, tid, st);
+            p_stage_store((it + 1) & 1);
+        }
+        if (wave == 0) fetch(it & 1);                          // slot it & 1 was read as `nxt` two barriers ago
+        __syncthreads();   // tile fully consumed, next tile fully staged, the tile after next published
+        cur_blkv = nxt_blkv; cur_t = nxt_t;
+        nxt_blkv = s_blkv[it & 1]; nxt_t = s_t[it & 1];
+    }
+    if (list_blkv != ~0u) write_lists();
+}
+
 // Pair-list kernel.  WAVES waves share the weight image; every wave is private otherwise (no workgroup barrier in the loop):
 // 32 pairs at a time, the rows of the NEXT group in flight in registers while the MFMAs of the current one run out of the wave's
 // LDS staging area.  The layer-1 activations are staged one K half at a time (tower_shared.h): the first half before quad 0,
@@ -520,6 +787,28 @@ int launch_tile_t(const TileArgs& a, hipStream_t s)
     return RECO_OK;
 }
 
+template <int G, bool L3, int SLOTS>
+int launch_tile_topk_t(const TileArgs& a, const TopkFuse& f, hipStream_t s)
+{
+    constexpr int THREADS = G <= 32 ? 768 : 512, TUBX = G <= 32 ? 24 : 16;     // as launch_tile_t
+    constexpr size_t lds = (size_t)(IMG_SIZE + 2 * (TI * QS + (G > 0 ? TI * (G + 4) : 0)) + 2 * TUBX * H1) * sizeof(float);
+    static_assert(lds <= 160 * 1024, "tile kernel LDS budget");
+    static bool attr[RECO_MAX_DEVICES] = {};
+    if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&tower_tile_topk_kernel<G, L3, THREADS, TUBX, SLOTS>), lds, attr)) return rc;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        RECO_CHECK_HIP(hipGetDevice(&dev));
+        RECO_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        if (n_cu <= 0) n_cu = 256;
+    }
+    const int64_t tiles = ceil_div64(a.N, TI) * ceil_div64(a.U, TUBX);
+    const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);   // one resident workgroup per CU
+    hipLaunchKernelGGL((tower_tile_topk_kernel<G, L3, THREADS, TUBX, SLOTS>), dim3(grid), dim3(THREADS), lds, s, a, f);
+    RECO_CHECK_LAUNCH();
+    return RECO_OK;
+}
+
 template <int G, bool L3, bool BIG>
 int launch_pairs_tb(const PairArgs& a, hipStream_t s)
 {
@@ -613,4 +902,38 @@ int gmf_launch_tile(const float* EUg, const float* EIg, const float* wp, const i
                        (size_t)16 * G * sizeof(float), s, a);
     RECO_CHECK_LAUNCH();
     return RECO_OK;
+}
+
+// ---- fused score + top-k (tower_tile_topk_kernel) ----
+int tower_tile_users_per_block(int G) { return G <= 32 ? 24 : 16; }
+
+// counters: [fresh | pad to 64 words | next_tile[blocks] | visits[blocks]], zeroed by the caller together with `partial`
+size_t tower_topk_counter_bytes(int G, int64_t U)
+{
+    return align_up((size_t)(64 + 2 * ceil_div64(U, tower_tile_users_per_block(G))) * sizeof(unsigned int), 256);
+}
+
+int tower_launch_tile_topk(int G, int has_l3, const float* img, const float* P, const float* Q,
+                           const float* EUg, const float* EIg, const int64_t* users, const int64_t* cands,
+                           int64_t user_base, int64_t n_users, int64_t n_items, int64_t U, int64_t N,
+                           float bp, int act, float lo, float hi, int32_t* oob,
+                           int k, int v_max, unsigned int* counters, unsigned long long* partial, hipStream_t s)
+{
+    if (U <= 0 || N <= 0) return RECO_OK;
+    RECO_REQUIRE(k >= 1 && k <= 128 && v_max >= 1 && v_max <= 1024, "fused top-k: k=%d / v_max=%d out of range", k, v_max);
+    RECO_REQUIRE(N < (1ll << 31) && ceil_div64(U, 16) < (1ll << 21), "fused top-k: problem too large for one launch");
+    TileArgs a{img, P, Q, EUg, EIg, users, cands, user_base, n_users, n_items, U, N, nullptr, 0, bp, act, lo, hi, oob, nullptr};
+    const int64_t blocks = ceil_div64(U, tower_tile_users_per_block(G));
+    TopkFuse f{k, v_max, counters, counters + 64, counters + 64 + blocks, partial};
+    if (k <= 64) {
+        if (G == 32 && has_l3) return launch_tile_topk_t<32, true, 1>(a, f, s);
+        if (G == 0 && has_l3) return launch_tile_topk_t<0, true, 1>(a, f, s);
+        if (G == 64 && !has_l3) return launch_tile_topk_t<64, false, 1>(a, f, s);
+    } else {
+        if (G == 32 && has_l3) return launch_tile_topk_t<32, true, 2>(a, f, s);
+        if (G == 0 && has_l3) return launch_tile_topk_t<0, true, 2>(a, f, s);
+        if (G == 64 && !has_l3) return launch_tile_topk_t<64, false, 2>(a, f, s);
+    }
+    reco_set_error("fused top-k tile kernel: unsupported configuration G=%d has_l3=%d", G, has_l3);
+    return RECO_EINVAL;
 }
