@@ -233,6 +233,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
         const float* s_g = s_q + TI * QS;
         const int64_t n0 = (tile % tiles_n) * TI;
         const int64_t u0 = (tile / tiles_n) * TUB;
+        const int g_n = a.N - n0 > 32 ? TI / 32 : 1;           // the ragged last tile: no MFMAs for a column group past the catalog
         tile_queue_fetch(a, tid, next + gridDim.x, &s_next[(it + 1) & 1]);     // the tile after next
         if (next < tiles) { tile_stage_load<G, THREADS>(a, (next % tiles_n) * TI, next / tiles_n == 0, tid, st); p_stage_load(next); }
         const float* s_p = s_pbuf + (it & 1) * TUB * H1;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
                     gu[c] = gr[c] * *reinterpret_cast<const f32x4*>(wpg + 4 * c);
             }
 #pragma unroll 1
-            for (int g = 0; g < TI / 32; ++g) {
+            for (int g = 0; g < g_n; ++g) {
                 // keep the (loop-invariant) weight-image reads inside the loop: hoisted, they would pin ~200 VGPRs
                 asm volatile("" ::: "memory");
                 const float* qrow = s_q + (g * 32 + j) * QS + 4 * h;
@@ -505,9 +506,10 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_topk_kernel
 #pragma unroll
                 for (int c = 0; c < G / 8; ++c) gu[c] = gr[c] * *reinterpret_cast<const f32x4*>(wpg + 4 * c);
             }
-            float held = 0.f;                                  // group 0's score of pair j, until group 1's is ready
+            float held[2] = {0.f, 0.f};                        // the two column groups' scores of pair j
 #pragma unroll 1
             for (int g = 0; g < TI / 32; ++g) {
+                if (n0 + g * 32 >= a.N) break;                   // the ragged last tile: no MFMAs for a group past the catalog
                 asm volatile("" ::: "memory");
                 const float* qrow = s_q + (g * 32 + j) * QS + 4 * h;
                 struct PQ { f32x4 q, p; };
@@ -535,18 +537,19 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_topk_kernel
                     }
                 }
                 const float sc = epilogue(part + __shfl_xor(part, 32) + a.bp, a.act, a.lo, a.hi);
-                if (g == 0) held = sc;
-                else {
-                    // lanes 0..31 offer group 0's scores (items n0 + j), lanes 32..63 group 1's (items n0 + 32 + j): item n0 + lane
-                    const float x = h == 0 ? held : sc;
-                    // one float compare decides the common case (no score of the tile row reaches the k-th key's score; NaN
-                    // on either side passes and is settled by the exact keys)
-                    const float tf = key_float((uint32_t)(thr0 >> 32));
-                    if (__ballot(!(x < tf)) != 0) {
-                        const int64_t n = n0 + lane;
-                        const u64 key = ((u64)float_key(x) << 32) | (uint32_t)~(uint32_t)n;
-                        offer<SLOTS>(L0, P0, key, n < a.N, thr0, f.k, lane);
-                    }
+                if (g == 0) held[0] = sc;
+                else held[1] = sc;
+            }
+            {
+                // lanes 0..31 offer group 0's scores (items n0 + j), lanes 32..63 group 1's (items n0 + 32 + j): item n0 + lane
+                const float x = h == 0 ? held[0] : held[1];
+                // one float compare decides the common case (no score of the tile row reaches the k-th key's score; NaN
+                // on either side passes and is settled by the exact keys)
+                const float tf = key_float((uint32_t)(thr0 >> 32));
+                const int64_t n = n0 + lane;
+                if (__ballot(n < a.N && !(x < tf)) != 0) {
+                    const u64 key = ((u64)float_key(x) << 32) | (uint32_t)~(uint32_t)n;
+                    offer<SLOTS>(L0, P0, key, n < a.N, thr0, f.k, lane);
                 }
             }
             }

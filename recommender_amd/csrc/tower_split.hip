@@ -314,6 +314,7 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tower_tile_split_kernel(TileA
         const float* s_g = s_q + TI * QS;
         const int64_t n0 = (tile % tiles_n) * TI;
         const int64_t u0 = (tile / tiles_n) * TUB;
+        const int g_n = a.N - n0 > 32 ? TI / 32 : 1;           // the ragged last tile: no MFMAs for a column group past the catalog
         tile_queue_fetch(a, tid, next + gridDim.x, &s_next[(it + 1) & 1]);     // the tile after next
         if (next < tiles) tile_stage_load<G>(a, (next % tiles_n) * TI, next / tiles_n == 0, tid, st);
 
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tower_tile_split_kernel(TileA
                 }
             }
 #pragma unroll 1
-            for (int g = 0; g < TI / 32; ++g) {
+            for (int g = 0; g < g_n; ++g) {
                 asm volatile("" ::: "memory");            // keep the weight reads inside the loop (see tower.hip)
                 const float* qrow = s_q + (g * 32 + j) * QS + 8 * h;
                 struct X1Tile {
