@@ -18,8 +18,23 @@
 #include "reco_common.h"
 #include "topk_shared.h"
 
+// Long-row scan shape, from same-box A/B runs on 256 x 1M, k = 100 (library variants through RECO_HIP_LIB):
+//   float4 loads in flight per lane x waves the rows are split into -> ms
+//   4 x 4096: 0.329   6 x 3072: 0.314   5 x 3072: 0.323   3 x 4096: 0.325   4 x 3072: 0.351   6 x 2560: 0.339
+//   6 x 4096: 0.413 (over 128 VGPRs: a fourth wave per SIMD no longer fits)   8 x 4096: 0.554   8 x 2048: 0.485
+// The list upkeep of a segment's warm-up (k ln(n/k) entrants), not the streaming, is what is left: fewer, longer segments win
+// as long as three waves per SIMD keep the loads covered.  Masked scans carry the mask registers too and stay at 4 x 4096.
 #ifndef RECO_TOPK_UN
-#define RECO_TOPK_UN 4       // float4 loads in flight per lane: 4 KB per wave, 16 MB over the chip at 4 waves per SIMD
+#define RECO_TOPK_UN 6
+#endif
+#ifndef RECO_TOPK_UN_MASKED
+#define RECO_TOPK_UN_MASKED 4
+#endif
+#ifndef RECO_TOPK_WAVES
+#define RECO_TOPK_WAVES 3072
+#endif
+#ifndef RECO_TOPK_WAVES_MASKED
+#define RECO_TOPK_WAVES_MASKED 4096
 #endif
 
 namespace {
@@ -44,7 +59,9 @@ struct TopkArgs {
 
 // VEC = 4: rows are 16-byte aligned (ld % 4 == 0): each lane loads float4s, two in flight per iteration (512 elements per
 // wave and iteration); VEC = 1: any alignment, one float per lane and load, four in flight.
-template <int SLOTS, int VEC>
+// MASKED = false: no mask operand at all (the mask registers that travel with the scores cost the unmasked scan a third of
+// its speed on long rows: 0.354 -> 0.475 ms on 256 x 1M when they were carried unconditionally).
+template <int SLOTS, int VEC, bool MASKED>
 __global__ __launch_bounds__(256) void topk_scan_kernel(TopkArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -63,9 +80,9 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(TopkArgs a)
         }
     }
     const float* src = a.scores + srow * a.ld;
-    const uint8_t* ex = a.exclude ? a.exclude + srow * a.ld_ex : nullptr;
-    const float* sf = a.seen ? a.seen + srow * a.ld_seen : nullptr;
-    const bool masked = ex != nullptr || sf != nullptr;
+    const uint8_t* ex = (MASKED && a.exclude) ? a.exclude + srow * a.ld_ex : nullptr;
+    const float* sf = (MASKED && a.seen) ? a.seen + srow * a.ld_seen : nullptr;
+    constexpr bool masked = MASKED;
 
     WaveList<SLOTS> L;
     L.clear();
@@ -75,7 +92,7 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(TopkArgs a)
     // (Measured and dropped in round 2: a float pre-filter "score >= k-th score" in front of the key build, per 256-element block
     // 0.354 -> 0.383 ms and per 64-element offer 0.354 -> 0.353 ms on 256 x 1M, k = 100: the key build is not what bounds the scan.)
     if constexpr (VEC == 4) {
-        constexpr int UN = RECO_TOPK_UN;
+        constexpr int UN = MASKED ? RECO_TOPK_UN_MASKED : RECO_TOPK_UN;
         // the masks travel with the scores: mk > 0 marks an excluded element.  (Read where they are applied -- after the scores
         // have arrived -- the mask loads were an exposed round trip per block: 6,040 x 3,706 with the float rating matrix as
         // the mask took 0.080 ms against 0.040 ms without a mask.)
@@ -94,7 +111,7 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(TopkArgs a)
                     if (n0 + 1 < s1) v[u].y = src[n0 + 1];
                     if (n0 + 2 < s1) v[u].z = src[n0 + 2];
                 }
-                if (!masked) continue;
+                if constexpr (!MASKED) continue;
                 f32x4 m = {0.f, 0.f, 0.f, 0.f};
                 if (sf) {
                     if (sf2 && whole) {
@@ -121,9 +138,10 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(TopkArgs a)
                 mk[u] = m;
             }
         };
-        f32x4 v[UN], vn[UN], mk[UN], mkn[UN];
+        constexpr int UM = MASKED ? UN : 1;
+        f32x4 v[UN], vn[UN], mk[UM], mkn[UM];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) mk[u] = mkn[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < UM; ++u) mk[u] = mkn[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         load(s0, v, mk);
         for (int64_t base = s0; base < s1; base += 256 * UN) {
             if (base + 256 * UN < s1) load(base + 256 * UN, vn, mkn);  // next iteration's loads fly under this one's compares
@@ -134,12 +152,17 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(TopkArgs a)
                     const int64_t n = base + u * 256 + 4 * lane + t;
                     const bool ok = n < s1;
                     float x = v[u][t];
-                    if (masked && mk[u][t] > 0.f) x = x * 0.f - 1e10f;   // helper.py:313: pred*(~seen) - seen*1e10
+                    if constexpr (MASKED) {
+                        if (mk[u][t] > 0.f) x = x * 0.f - 1e10f;         // helper.py:313: pred*(~seen) - seen*1e10
+                    }
                     const u64 key = ((u64)float_key(x) << 32) | (uint32_t)~(uint32_t)n;
                     offer<SLOTS>(L, P, key, ok, thr, a.k, lane);
                 }
 #pragma unroll
-            for (int u = 0; u < UN; ++u) { v[u] = vn[u]; mk[u] = mkn[u]; }
+            for (int u = 0; u < UN; ++u) {
+                v[u] = vn[u];
+                if constexpr (MASKED) mk[u] = mkn[u];
+            }
         }
     } else {
         for (int64_t base = s0; base < s1; base += 256) {
@@ -306,12 +329,11 @@ __global__ __launch_bounds__(256) void topk_lane_kernel(TopkArgs a)
     }
 }
 
-int choose_splits(int64_t rows, int64_t N, int k)
+int choose_splits(int64_t rows, int64_t N, int k, bool masked)
 {
-    // aim for >= 4096 waves (4 per SIMD) while keeping segments long enough to amortise the list: every segment pays its own
-    // k ln(segment / k) entrants, so fewer, longer segments do less work (256 x 1M, k = 100: 0.39 ms at 8192 waves, 0.35 ms at
-    // 4096, 0.53 ms at 2048 where the loads are no longer hidden)
-    int64_t want = ceil_div64(4096, rows);
+    // enough waves to cover the loads (3-4 per SIMD) while keeping segments long enough to amortise the list: every segment
+    // pays its own k ln(segment / k) entrants, so fewer, longer segments do less work
+    int64_t want = ceil_div64(masked ? RECO_TOPK_WAVES_MASKED : RECO_TOPK_WAVES, rows);
     int64_t max_by_len = N / 4096 > 0 ? N / 4096 : 1;
     int64_t s = want < max_by_len ? want : max_by_len;
     if (s < 1) s = 1;
@@ -339,7 +361,8 @@ int launch_topk_merge(const unsigned long long* partial, int64_t rows, int split
 size_t topk_workspace_bytes(int64_t rows, int64_t N, int k)
 {
     if (rows <= 0 || N <= 0 || k <= 0) return 0;
-    const int splits = choose_splits(rows, N, k);
+    const int a = choose_splits(rows, N, k, false), b = choose_splits(rows, N, k, true);
+    const int splits = a > b ? a : b;                 // the caller may or may not bring a mask
     return splits > 1 ? align_up((size_t)rows * splits * k * sizeof(u64), 256) : 0;
 }
 
@@ -378,7 +401,7 @@ int launch_topk_rows_ex(const float* scores, int64_t rows, int64_t N, int64_t ld
         RECO_CHECK_LAUNCH();
         return RECO_OK;
     }
-    a.splits = choose_splits(rows, N, k);
+    a.splits = choose_splits(rows, N, k, exclude != nullptr || seen != nullptr);
     if (a.splits > 1) {
         const size_t need = (size_t)rows * a.splits * k * sizeof(u64);
         if (ws == nullptr || ws_bytes < need) {
@@ -393,13 +416,21 @@ int launch_topk_rows_ex(const float* scores, int64_t rows, int64_t N, int64_t ld
     RECO_REQUIRE(blocks < (1ll << 31), "topk grid too large");
     const bool vec4 = N >= 1024 && ld % 4 == 0 && (uintptr_t)scores % 16 == 0;      // segment starts are multiples of 64 elements;
     // short rows keep whole 64-element chunks per offer (N = 100: 0.10 ms scalar vs 0.16 ms with quarter-filled chunks)
+    const bool masked = exclude != nullptr || seen != nullptr;
+    const dim3 grid((unsigned)blocks), block(256);
+#define RECO_TOPK_LAUNCH(SLOTS, VEC)                                                                        \
+    do {                                                                                                    \
+        if (masked) hipLaunchKernelGGL((topk_scan_kernel<SLOTS, VEC, true>), grid, block, 0, s, a);          \
+        else hipLaunchKernelGGL((topk_scan_kernel<SLOTS, VEC, false>), grid, block, 0, s, a);                \
+    } while (0)
     if (k <= 64) {
-        if (vec4) hipLaunchKernelGGL((topk_scan_kernel<1, 4>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((topk_scan_kernel<1, 1>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+        if (vec4) RECO_TOPK_LAUNCH(1, 4);
+        else RECO_TOPK_LAUNCH(1, 1);
     } else {
-        if (vec4) hipLaunchKernelGGL((topk_scan_kernel<2, 4>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((topk_scan_kernel<2, 1>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+        if (vec4) RECO_TOPK_LAUNCH(2, 4);
+        else RECO_TOPK_LAUNCH(2, 1);
     }
+#undef RECO_TOPK_LAUNCH
     RECO_CHECK_LAUNCH();
     if (a.splits > 1) {
         const int64_t mblocks = ceil_div64(rows, 4);
