@@ -462,12 +462,17 @@ static const int64_t kTopkExtraRows = 8192;               // bound of rows*split
 // select reads rows as float4 (N = 3533 rows would otherwise start at odd 4-byte offsets)
 static int64_t score_ld(int64_t N) { return (N + 31) / 32 * 32; }
 
+// Whole user blocks per chunk: the tile kernels work on blocks of 24 (NeuMF shapes) or 16 (Hybrid head) users, and a chunk that
+// ends inside a block leaves that block's waves half idle in EVERY chunk (1,024 users x 1M items went in chunks of 268 = 11
+// blocks + 4 users: 46 block passes instead of 43; in chunks of 240 the step measured 158.1 -> 157.6 ms).
+static int64_t whole_blocks(int64_t c) { return c >= 48 ? c - c % 48 : c; }
+
 static int64_t default_chunk(int64_t U, int64_t N)
 {
     if (N <= 0) return U;
     int64_t c = (int64_t)(kScoreChunkBytes / ((size_t)score_ld(N) * sizeof(float)));
     if (c < 32) c = 32;
-    return c < U ? c : U;
+    return c < U ? whole_blocks(c) : U;
 }
 
 static size_t topk_chunk_bytes(int64_t Uc, int64_t N, int k)
@@ -477,17 +482,21 @@ static size_t topk_chunk_bytes(int64_t Uc, int64_t N, int k)
 }
 
 // ---- fused form: tower_tile_topk_kernel keeps every user's running top-k in registers, the score rows never reach HBM ----
-// Partial lists ("visitor slots", tower.hip) per user block: a workgroup that joins a block takes one, so few blocks (a request
-// for a handful of users over a long catalog: ONE block for all 256 CUs) need many, many blocks need few.  About three visits
-// per CU over a launch: 1024 users x 1M items (43 blocks) with 8 slots left two blocks short of helpers at the end (+11 %).
-// A workgroup visits a block at most once, so one slot per CU is always enough.
+// Partial lists ("visitor slots", tower.hip) per user block: a workgroup that joins a block takes one.  Many blocks need few
+// (about three visits per CU over a launch).  Few blocks -- fewer than half the CUs: a request for a handful of users over a
+// long catalog, or 1,024 users x 1M items = 43 blocks -- need one per CU, because whichever blocks are still running at the end
+// must be able to take in every workgroup that has run out of work (with 18 slots two of those 43 blocks ended 5 % late).
+// Lists nobody wrote are cleared and skipped, so the slots are capped where that clearing would show: N / (8 k).
 static const int kFuseVisitorsMin = 4, kFuseVisitorsMax = 256;
 static const size_t kFusePartialBytes = (size_t)256 << 20;   // user chunks are sized so that the partial lists stay below this
 
-static int fuse_visitors(int G, int64_t Uc)
+static int fuse_visitors(int G, int64_t Uc, int64_t N, int k)
 {
     const int64_t blocks = (Uc + tower_tile_users_per_block(G) - 1) / tower_tile_users_per_block(G);
     int64_t v = (3 * 256 + blocks - 1) / (blocks > 0 ? blocks : 1);
+    if (blocks < 128) v = kFuseVisitorsMax;
+    const int64_t cap = N / (8 * (int64_t)k);
+    if (v > cap) v = cap;
     return (int)(v < kFuseVisitorsMin ? kFuseVisitorsMin : (v > kFuseVisitorsMax ? kFuseVisitorsMax : v));
 }
 
@@ -495,7 +504,7 @@ static size_t fused_partial_bytes(int64_t Uc, int v, int k) { return align_up((s
 
 static size_t fused_chunk_bytes(int G, int64_t Uc, int64_t N, int k)
 {
-    return kQueueBytes + proj_bytes(N) + proj_bytes(Uc) + tower_topk_counter_bytes(G, Uc) + fused_partial_bytes(Uc, fuse_visitors(G, Uc), k);
+    return kQueueBytes + proj_bytes(N) + proj_bytes(Uc) + tower_topk_counter_bytes(G, Uc) + fused_partial_bytes(Uc, fuse_visitors(G, Uc, N, k), k);
 }
 
 static int64_t fused_default_chunk(int64_t U, int k)
@@ -503,16 +512,27 @@ static int64_t fused_default_chunk(int64_t U, int k)
     // large chunks run at the minimum list count; small ones hold <= ~768 lists per 24 users, 19 MB at k = 128
     int64_t c = (int64_t)(kFusePartialBytes / ((size_t)kFuseVisitorsMin * k * sizeof(uint64_t)));
     if (c < 32) c = 32;
-    return c < U ? c : U;
+    return c < U ? whole_blocks(c) : U;
 }
 
 // Only the exact MFMA tower has the fused kernel (GMF-only models and the split mode keep score rows in the workspace).
 static bool fused_topk_available(const reco_tower* t) { return t->mfma && !t->img_split; }
 
+// reco_tower_score_topk itself takes the fused form where it measured faster: mask-free calls whose score rows would not fit one
+// user chunk (1,024 x 1M, k = 100: 157.6 -> 154.3 ms, five tile launches + five scans against one launch + a merge; where one
+// chunk suffices the two-kernel form is 0-5 % ahead, DESIGN section 3, fused kernel).
+static bool fused_topk_preferred(const reco_tower* t, const uint8_t* exclude, int64_t U, int64_t N)
+{
+    return fused_topk_available(t) && !exclude && U > default_chunk(U, N);
+}
+
 extern "C" size_t reco_tower_topk_workspace_bytes(int64_t U, int64_t N, int k)
 {
     if (U <= 0 || N <= 0 || k <= 0) return 0;
-    return topk_chunk_bytes(default_chunk(U, N), N, k);
+    // enough for either form and either user-block size: the handle and the mask are not known here
+    const int64_t Uf = fused_default_chunk(U, k);
+    const size_t a = topk_chunk_bytes(default_chunk(U, N), N, k), b = fused_chunk_bytes(32, Uf, N, k), c = fused_chunk_bytes(64, Uf, N, k);
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
 extern "C" size_t reco_tower_topk_fused_workspace_bytes(const reco_tower_t* t, int64_t U, int64_t N, int k)
@@ -527,7 +547,7 @@ static int score_topk_fused(reco_tower_t* t, const int64_t* users, int64_t user_
 {
     const reco_tower_desc_t& d = t->d;
     int64_t Uc = fused_default_chunk(U, k);
-    while (Uc > 1 && fused_chunk_bytes(t->G, Uc, N, k) > ws_bytes) Uc = Uc / 2;
+    while (Uc > 1 && fused_chunk_bytes(t->G, Uc, N, k) > ws_bytes) Uc = whole_blocks(Uc / 2);
     if (!ws || fused_chunk_bytes(t->G, Uc, N, k) > ws_bytes) {
         reco_set_error("%s: workspace too small (%zu bytes; one user needs %zu)", who, ws_bytes, fused_chunk_bytes(t->G, 1, N, k));
         return RECO_ENOMEM;
@@ -537,7 +557,7 @@ static int score_topk_fused(reco_tower_t* t, const int64_t* users, int64_t user_
     float* P = reinterpret_cast<float*>(w); w += proj_bytes(Uc);
     unsigned int* counters = reinterpret_cast<unsigned int*>(w);
     const size_t counter_bytes = tower_topk_counter_bytes(t->G, Uc);       // whole chunks and the last, shorter one share this split
-    const int64_t list_room = Uc * fuse_visitors(t->G, Uc);                // partial lists the workspace was sized for
+    const int64_t list_room = Uc * fuse_visitors(t->G, Uc, N, k);                // partial lists the workspace was sized for
     unsigned long long* partial = reinterpret_cast<unsigned long long*>(w + counter_bytes);
     const bool cached_q = !cands && N == d.n_items && U <= kServingUsers && t->Q;     // as the unfused form below
     int rc = RECO_OK;
@@ -549,7 +569,7 @@ static int score_topk_fused(reco_tower_t* t, const int64_t* users, int64_t user_
         const float* urows = ul ? d.user_mlp : d.user_mlp + (user_base + c0) * d.dm;
         if ((rc = tower_project(t, urows, ul, d.n_users, n, nullptr, nullptr, 0, 0, P, nullptr, oob, s))) return rc;
         // hand-out counters and partial lists start at zero (a list nobody wrote reads as empty)
-        int v = fuse_visitors(t->G, n);                                    // a short last chunk may take more lists per block
+        int v = fuse_visitors(t->G, n, N, k);                                    // a short last chunk may take more lists per block
         if ((int64_t)v * n > list_room) v = (int)(list_room / n);
         RECO_CHECK_HIP(hipMemsetAsync(counters, 0, counter_bytes + fused_partial_bytes(n, v, k), s));
         {
@@ -575,9 +595,12 @@ static int score_topk_impl(reco_tower_t* t, const int64_t* users, int64_t user_b
     int rc = check_ranges(t, users, user_base, U, cands, N, who);
     if (rc) return rc;
 
+    if (fused_topk_preferred(t, exclude, U, N))
+        return score_topk_fused(t, users, user_base, U, cands, N, k, out_ids, out_scores, oob, ws, ws_bytes, s, who);
+
     // largest user chunk the workspace admits
     int64_t Uc = default_chunk(U, N);
-    while (Uc > 1 && topk_chunk_bytes(Uc, N, k) > ws_bytes) Uc = Uc / 2;
+    while (Uc > 1 && topk_chunk_bytes(Uc, N, k) > ws_bytes) Uc = whole_blocks(Uc / 2);
     if (!ws || topk_chunk_bytes(Uc, N, k) > ws_bytes) {
         reco_set_error("%s: workspace too small (%zu bytes; one user needs %zu)", who, ws_bytes, topk_chunk_bytes(1, N, k));
         return RECO_ENOMEM;

@@ -33,6 +33,9 @@
 #ifndef RECO_TOPK_WAVES
 #define RECO_TOPK_WAVES 3072
 #endif
+#ifndef RECO_TOPK_RING
+#define RECO_TOPK_RING 64    // pending candidates per wave before a flush
+#endif
 #ifndef RECO_TOPK_WAVES_MASKED
 #define RECO_TOPK_WAVES_MASKED 4096
 #endif
@@ -84,9 +87,11 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(TopkArgs a)
     const float* sf = (MASKED && a.seen) ? a.seen + srow * a.ld_seen : nullptr;
     constexpr bool masked = MASKED;
 
+    __shared__ __attribute__((aligned(16))) u64 s_ring[4][64];       // pending candidates, one ring per wave
+    u64* ring = s_ring[threadIdx.x >> 6];
     WaveList<SLOTS> L;
     L.clear();
-    Pending P;
+    RingPending P;
     P.clear();
     u64 thr = 0;
     // (Measured and dropped in round 2: a float pre-filter "score >= k-th score" in front of the key build, per 256-element block
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(TopkArgs a)
                         if (mk[u][t] > 0.f) x = x * 0.f - 1e10f;         // helper.py:313: pred*(~seen) - seen*1e10
                     }
                     const u64 key = ((u64)float_key(x) << 32) | (uint32_t)~(uint32_t)n;
-                    offer<SLOTS>(L, P, key, ok, thr, a.k, lane);
+                    offer_ring<SLOTS, RECO_TOPK_RING>(L, P, ring, key, ok, thr, a.k, lane);
                 }
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
@@ -179,11 +184,11 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(TopkArgs a)
             for (int t = 0; t < 4; ++t) {
                 const int64_t n = base + t * 64 + lane;
                 const u64 key = ((u64)float_key(v[t]) << 32) | (uint32_t)~(uint32_t)n;
-                offer<SLOTS>(L, P, key, ok[t], thr, a.k, lane);
+                offer_ring<SLOTS, RECO_TOPK_RING>(L, P, ring, key, ok[t], thr, a.k, lane);
             }
         }
     }
-    flush<SLOTS>(L, P, thr, a.k, lane);
+    flush_ring<SLOTS, RECO_TOPK_RING>(L, P, ring, thr, a.k, lane);
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         const int r = s * 64 + lane;

@@ -185,4 +185,72 @@ __device__ __forceinline__ void offer(WaveList<SLOTS>& L, Pending& P, u64 key, b
     P.n += c;
 }
 
+// ---- the same batching with the pending keys in LDS ----
+// ring: RING 64-bit slots of LDS owned by the wave.  A candidate is stored at ring[n + (candidates in lower lanes)] by a plain
+// ds_write (nothing is waited for; the register form above pays two ds_permute round trips per offer that holds a candidate),
+// and a flush sorts the pending keys by RANK: every lane counts the pending keys above its own through broadcast LDS reads --
+// independent reads and compares instead of the 21 dependent cross-lane stages of a bitonic network -- and stores its key at
+// its rank.  LDS operations of one wave execute in issue order, so no barrier is needed between the phases.
+struct RingPending {
+    int n;       // wave-uniform
+    __device__ __forceinline__ void clear() { n = 0; }
+};
+
+template <int SLOTS, int RING>
+__device__ __forceinline__ void flush_ring(WaveList<SLOTS>& L, RingPending& P, u64* ring, u64& thr, int k, int lane)
+{
+    static_assert(RING <= 64, "one pending key per lane at most");
+    if (P.n == 0) return;
+    const int n = P.n;
+    P.n = 0;
+    const u64 mine = lane < n ? ring[lane] : 0;
+    if (n <= SERIAL_INSERTS_MAX) {
+        for (int i = 0; i < n; ++i) {
+            const u64 x = bcast(mine, i);
+            if (x > thr) {               // thr may have risen since the key was collected
+                L.insert(x, lane);
+                thr = L.kth(k);
+            }
+        }
+        return;
+    }
+    int rank = 0;
+    for (int j = 0; j + 1 < n; j += 2) {                    // two keys per broadcast ds_read_b128
+        typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+        const u64x2 o = *reinterpret_cast<const u64x2*>(ring + j);
+        rank += (o.x > mine) + (o.y > mine);
+    }
+    if (n & 1) rank += ring[n - 1] > mine;
+    // keys are distinct (they carry the position), so the ranks of the n pending keys are 0 .. n-1; the other lanes (key 0,
+    // rank n) keep their own slot
+    ring[lane < n ? rank : lane] = mine;
+    const u64 sorted = lane < RING ? ring[lane] : 0;
+    L.merge_sorted(sorted, lane);
+    thr = L.kth(k);
+}
+
+template <int SLOTS, int RING>
+__device__ __forceinline__ void offer_ring(WaveList<SLOTS>& L, RingPending& P, u64* ring, u64 key, bool valid, u64& thr, int k, int lane)
+{
+    bool cand = valid && key > thr;
+    u64 m = __ballot(cand);
+    int c = __popcll(m);
+    if (c == 0) return;
+    if (P.n + c > RING) {
+        flush_ring<SLOTS, RING>(L, P, ring, thr, k, lane);
+        cand = cand && key > thr;
+        m = __ballot(cand);
+        c = __popcll(m);
+        if (c == 0) return;
+        if (c > RING) {              // RING < 64 only: more candidates in one offer than the ring holds -> straight into the list
+            L.merge_sorted(wave_sort_desc(cand ? key : 0, lane), lane);
+            thr = L.kth(k);
+            return;
+        }
+    }
+    const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (cand) ring[P.n + below] = key;
+    P.n += c;
+}
+
 }  // namespace

@@ -339,7 +339,10 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_topk_kernel
     float* s_img = smem;
     float* s_buf = smem + IMG_SIZE;
     constexpr int NP = (TUB * (H1 / 4) + TILE_THREADS - 1) / TILE_THREADS;
-    float* s_pbuf = s_buf + 2 * BUF;
+    // The workgroup stays with one user block for many tiles, so the block's P rows are staged ONCE per block (single buffer,
+    // an extra barrier at the switch) and the space of the second buffer holds the pending-candidate rings of the block's users.
+    float* s_pbuf = s_buf + 2 * BUF;                            // [TUB][H1]
+    u64* s_ring = reinterpret_cast<u64*>(s_pbuf + TUB * H1);     // [TUB][64]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -432,23 +435,25 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_topk_kernel
             if (i < TUB * (H1 / 4) && u < a.U) pst[s] = reinterpret_cast<const f32x4*>(a.P + u * H1)[i & 31];
         }
     };
-    auto p_stage_store = [&](int buf) {
+    auto p_stage_store = [&]() {
 #pragma unroll
         for (int s = 0; s < NP; ++s)
             if (tid + s * TILE_THREADS < TUB * (H1 / 4))
-                reinterpret_cast<f32x4*>(s_pbuf + buf * TUB * H1)[tid + s * TILE_THREADS] = pst[s];
+                reinterpret_cast<f32x4*>(s_pbuf)[tid + s * TILE_THREADS] = pst[s];
     };
 
     // ---- per-wave top-k state: one sorted list per owned user ----
     WaveList<SLOTS> L0, L1;
-    Pending P0, P1;
+    RingPending P0, P1;
+    u64* const ring0 = s_ring + wave * 64;                      // rings of this wave's two users
+    u64* const ring1 = s_ring + (wave + WAVES) * 64;
     u64 thr0 = 0, thr1 = 0;
     L0.clear(); L1.clear(); P0.clear(); P1.clear();
     unsigned list_blkv = ~0u;                                  // block / slot the lists belong to (~0u: nothing collected yet)
     auto write_lists = [&]() {                                 // this wave's two users of block list_blkv -> their partial lists
         const unsigned blk = list_blkv >> LIST_SHIFT, v = list_blkv & ((1u << LIST_SHIFT) - 1u);
-        flush<SLOTS>(L0, P0, thr0, f.k, lane);
-        flush<SLOTS>(L1, P1, thr1, f.k, lane);
+        flush_ring<SLOTS, 64>(L0, P0, ring0, thr0, f.k, lane);
+        flush_ring<SLOTS, 64>(L1, P1, ring1, thr1, f.k, lane);
 #pragma unroll
         for (int ui = 0; ui < UPW; ++ui) {
             const int64_t u = (int64_t)blk * TUB + wave + ui * WAVES;
@@ -472,7 +477,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_topk_kernel
         tile_stage_load<G, THREADS>(a, (int64_t)cur_t * TI, (cur_blkv >> LIST_SHIFT) == 0, tid, st);
         tile_stage_store<G, THREADS>(s_buf, s_buf + TI * QS, tid, st);
         p_stage_load(cur_blkv >> LIST_SHIFT);
-        p_stage_store(0);
+        p_stage_store();
     }
     __syncthreads();
     unsigned nxt_blkv = s_blkv[1], nxt_t = s_t[1];
@@ -483,8 +488,8 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_topk_kernel
         const int64_t n0 = (int64_t)cur_t * TI;
         const int64_t u0 = (int64_t)(cur_blkv >> LIST_SHIFT) * TUB;
         if (wave == 0) fetch_issue();                           // the tile after next: claimed now, published below
-        if (nxt_t != ~0u) { tile_stage_load<G, THREADS>(a, (int64_t)nxt_t * TI, (nxt_blkv >> LIST_SHIFT) == 0, tid, st); p_stage_load(nxt_blkv >> LIST_SHIFT); }
-        const float* s_p = s_pbuf + (it & 1) * TUB * H1;
+        if (nxt_t != ~0u) { tile_stage_load<G, THREADS>(a, (int64_t)nxt_t * TI, (nxt_blkv >> LIST_SHIFT) == 0, tid, st); }
+        const float* s_p = s_pbuf;
         if (cur_blkv != list_blkv) {                           // the workgroup moved to another block (or holds its first tile)
             if (list_blkv != ~0u) write_lists();
             list_blkv = cur_blkv;
@@ -549,21 +554,25 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_topk_kernel
                 const int64_t n = n0 + lane;
                 if (__ballot(n < a.N && !(x < tf)) != 0) {
                     const u64 key = ((u64)float_key(x) << 32) | (uint32_t)~(uint32_t)n;
-                    offer<SLOTS>(L0, P0, key, n < a.N, thr0, f.k, lane);
+                    offer_ring<SLOTS, 64>(L0, P0, ui == 0 ? ring0 : ring1, key, n < a.N, thr0, f.k, lane);
                 }
             }
             }
             { const WaveList<SLOTS> tl = L0; L0 = L1; L1 = tl; }
-            { const Pending tp = P0; P0 = P1; P1 = tp; }
+            { const RingPending tp = P0; P0 = P1; P1 = tp; }
             { const u64 tt = thr0; thr0 = thr1; thr1 = tt; }
         }
         if (nxt_t != ~0u) {
             float* d_q = s_buf + ((it + 1) & 1) * BUF;
             tile_stage_store<G, THREADS>(d_q, d_q + TI * QS, tid, st);
-            p_stage_store((it + 1) & 1);
         }
         if (wave == 0) fetch(it & 1);                          // slot it & 1 was read as `nxt` two barriers ago
         __syncthreads();   // tile fully consumed, next tile fully staged, the tile after next published
+        if (nxt_t != ~0u && (nxt_blkv >> LIST_SHIFT) != (cur_blkv >> LIST_SHIFT)) {     // the workgroup moves to another user block:
+            p_stage_load(nxt_blkv >> LIST_SHIFT);                                        // its P rows replace the old block's
+            p_stage_store();
+            __syncthreads();
+        }
         cur_blkv = nxt_blkv; cur_t = nxt_t;
         nxt_blkv = s_blkv[it & 1]; nxt_t = s_t[it & 1];
     }
@@ -794,7 +803,9 @@ template <int G, bool L3, int SLOTS>
 int launch_tile_topk_t(const TileArgs& a, const TopkFuse& f, hipStream_t s)
 {
     constexpr int THREADS = G <= 32 ? 768 : 512, TUBX = G <= 32 ? 24 : 16;     // as launch_tile_t
-    constexpr size_t lds = (size_t)(IMG_SIZE + 2 * (TI * QS + (G > 0 ? TI * (G + 4) : 0)) + 2 * TUBX * H1) * sizeof(float);
+    // image | two item-side buffers | one block of P rows | one 64-key ring per user (the same total as launch_tile_t's)
+    constexpr size_t lds = (size_t)(IMG_SIZE + 2 * (TI * QS + (G > 0 ? TI * (G + 4) : 0)) + TUBX * H1) * sizeof(float) +
+                           (size_t)TUBX * 64 * sizeof(unsigned long long);
     static_assert(lds <= 160 * 1024, "tile kernel LDS budget");
     static bool attr[RECO_MAX_DEVICES] = {};
     if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&tower_tile_topk_kernel<G, L3, THREADS, TUBX, SLOTS>), lds, attr)) return rc;

@@ -130,3 +130,16 @@ def test_fused_hybrid_head_shape_with_tables():
             full = head.score_matrix(zu, zi)
             oid, oval = O.topk_rows(full.cpu().numpy(), k)
             assert np.array_equal(fused[0].cpu().numpy(), oid) and np.array_equal(fused[1].cpu().numpy(), oval)
+
+
+def test_score_topk_takes_the_fused_form_when_the_score_rows_need_several_user_chunks():
+    """300 users x 1M items = 1.2 GB of score rows: more than one 1 GiB user chunk, so reco_tower_score_topk itself scores and
+    selects in one kernel.  An all-zero mask still takes the two-kernel form (chunks of 240 users): same bits."""
+    m, t = _model(512, 1_000_000, 12, scale=10.0)
+    users = (100, 300)
+    got = t.score_topk(users, 100)
+    zeros = torch.zeros((300, 1_000_000), dtype=torch.uint8, device="cuda")
+    want = t.score_topk(users, 100, exclude=zeros)
+    assert _same(got, want)
+    ids = got[0].cpu().numpy()
+    assert (ids >= 0).all() and (ids < 1_000_000).all() and all(len(set(r)) == 100 for r in ids[:16])

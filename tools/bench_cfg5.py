@@ -63,7 +63,7 @@ def _run(dev, world, rank, launched, upg, steps, warmup, precision):
     for i in range(warmup):
         step(i)
     L = _lib.lib()
-    cap = steps * (upg // 32 + 2) + 4                 # one tile-kernel launch per user chunk (256 users at 1 M items)
+    cap = steps * (upg // 32 + 2) + 4                 # one tile-kernel launch per user chunk (split mode: 240 users at 1 M items)
     _lib.check(L.reco_profile_enable(cap))
     fence()
     t0 = time.perf_counter()
@@ -92,7 +92,8 @@ def _run(dev, world, rank, launched, upg, steps, warmup, precision):
     tile_s = tile_ms_total * 1e-3
     roofline = None
     if n.value and tile_s > 0:
-        roofline = {"bound": "mfma", "kernel": "tower_tile%s_kernel<32,true>" % ("_split" if precision == "bf16x3" else ""),
+        # the exact mode scores and selects in one kernel here (the score rows of 1,024 users would need five user chunks)
+        roofline = {"bound": "mfma", "kernel": "tower_tile_split_kernel<32,true>" if precision == "bf16x3" else "tower_tile_topk_kernel<32,true>",
                     "achieved": pairs_rank * flop_exec / tile_s / 1e12, "peak": peak, "unit": "TFLOP/s",
                     "frac": pairs_rank * flop_exec / tile_s / 1e12 / peak, "flop_per_pair_executed": flop_exec,
                     "kernel_ms": tile_ms_total / n.value, "launches_timed": n.value, "pairs_per_launch": pairs_rank // n.value,

@@ -28,10 +28,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="", help="comma-separated indices into SHAPES (default: all)")
     ap.add_argument("--reps", type=int, default=0, help="override the per-shape repeat count (counter passes: 2)")
+    ap.add_argument("--custom", default="", help="extra shapes as users:items:k:reps, comma separated (instead of SHAPES)")
     args = ap.parse_args()
     from recommender_amd.helpers import NCF
     dev = torch.device("cuda", 0)
     picked = [SHAPES[int(i)] for i in args.shapes.split(",")] if args.shapes else SHAPES
+    if args.custom:
+        picked = []
+        for spec in args.custom.split(","):
+            u, n, k, r = (int(x) for x in spec.split(":"))
+            picked.append((max(u, 2048), n, u, k, r))
     for n_users, n_items, U, k, reps in picked:
         reps = args.reps or reps
         torch.manual_seed(0)
