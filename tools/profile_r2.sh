@@ -19,10 +19,10 @@ echo "gather WRITE_SIZE done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_trace" -- python3 "$ROOT/bench.py" > "$OUT/bench_prof.json" 2> "$OUT/bench_prof.err"
 echo "bench trace done"
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -s KILL 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/bench_$c" -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-split > "$OUT/bench_$c.json" 2> "$OUT/bench_$c.err"
+  timeout -s KILL 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/bench_$c" -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-split --no-cfg5 > "$OUT/bench_$c.json" 2> "$OUT/bench_$c.err"
   echo "bench $c done"
 done
-timeout -s KILL 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d "$OUT/bench_mfma" -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-split > "$OUT/bench_mfma.json" 2> "$OUT/bench_mfma.err"
+timeout -s KILL 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d "$OUT/bench_mfma" -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-split --no-cfg5 > "$OUT/bench_mfma.json" 2> "$OUT/bench_mfma.err"
 echo "bench mfma done"
 cd "$ROOT"
 python3 tools/kernel_trace_summary.py "$OUT/kb_trace" > "$OUT/kernel_bench_trace.json"
