@@ -89,6 +89,10 @@ template <bool L3, typename X1>
 __device__ __forceinline__ float tower_mlp_part(const float* s_img, int lane, X1 x1)
 {
     const int h = lane >> 5;
+    // A wave inside the MFMA body outranks its SIMD's other waves while they stage tiles, claim work or keep lists: same-box A/B
+    // (RECO_HIP_LIB variants) cfg2 tile kernel -0.4 %, cfg5 -0.7 %, 11.5 M-pair list -1.6 %; the 8-wave Hybrid head shape lost
+    // 0.4 % with it and stays at the default priority.
+    if constexpr (L3) __builtin_amdgcn_s_setprio(1);
     f32x16 acc0 = bias16(s_img + IMG_B2, h);
     f32x16 acc1 = bias16(s_img + IMG_B2 + 32, h);
     const f32x4* w2 = reinterpret_cast<const f32x4*>(s_img + IMG_W2) + lane;
@@ -130,7 +134,8 @@ __device__ __forceinline__ float tower_mlp_part(const float* s_img, int lane, X1
         __builtin_amdgcn_sched_barrier(0);
         x = xn; a0 = a0n; a1 = a1n;
     }
-    float part = 0.f;
+    // independent work of the caller (the GMF half of the predict layer) fills the wait for layer 2's last accumulators
+    float part = x1.between();
 #ifdef RECO_ABL_NO_L3
     return acc0[0] + acc1[0];
 #endif
@@ -158,6 +163,7 @@ __device__ __forceinline__ float tower_mlp_part(const float* s_img, int lane, X1
             __builtin_amdgcn_sched_barrier(0);
             a = an;
         }
+        __builtin_amdgcn_s_setprio(0);
         part = dot16_relu(acc3, s_img + IMG_WPM, h, part);
     } else {
         part = dot16_relu(acc0, s_img + IMG_WPM, h, part);
@@ -267,19 +273,25 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
                     __device__ __forceinline__ void pre(int) const {}
                     __device__ __forceinline__ f32x4 finish(int, const PQ& v) const { return relu4(v.p + v.q); }
                     __device__ __forceinline__ f32x4 passthrough(const PQ& v) const { return v.q; }
-                };
-                float part = tower_mlp_part<L3>(s_img, lane, X1TileLds{qrow, s_p + uu * H1 + 4 * h});
-                if constexpr (G > 0) {
-                    const float* grow = s_g + (g * 32 + j) * GS + h * (G / 2);
+                    const float* grow;     // this pair's GMF item row half in LDS
+                    const f32x4* gu;       // the user's GMF row half, predict weights folded in
+                    __device__ __forceinline__ float between() const
+                    {
+                        float part = 0.f;
+                        if constexpr (G > 0) {
 #pragma unroll
-                    for (int c = 0; c < G / 8; ++c) {
-                        const f32x4 gi = *reinterpret_cast<const f32x4*>(grow + 4 * c);
-                        part = fmaf(gu[c].x, gi.x, part);
-                        part = fmaf(gu[c].y, gi.y, part);
-                        part = fmaf(gu[c].z, gi.z, part);
-                        part = fmaf(gu[c].w, gi.w, part);
+                            for (int c = 0; c < G / 8; ++c) {
+                                const f32x4 gi = *reinterpret_cast<const f32x4*>(grow + 4 * c);
+                                part = fmaf(gu[c].x, gi.x, part);
+                                part = fmaf(gu[c].y, gi.y, part);
+                                part = fmaf(gu[c].z, gi.z, part);
+                                part = fmaf(gu[c].w, gi.w, part);
+                            }
+                        }
+                        return part;
                     }
-                }
+                };
+                const float part = tower_mlp_part<L3>(s_img, lane, X1TileLds{qrow, s_p + uu * H1 + 4 * h, s_g + (g * 32 + j) * GS + h * (G / 2), gu});
                 const float total = part + __shfl_xor(part, 32) + a.bp;
                 const int64_t n = n0 + g * 32 + j;
                 if (h == 0 && n < a.N) a.out[u * a.ld_out + n] = epilogue(total, a.act, a.lo, a.hi);
@@ -528,19 +540,25 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_topk_kernel
                     __device__ __forceinline__ void pre(int) const {}
                     __device__ __forceinline__ f32x4 finish(int, const PQ& v) const { return relu4(v.p + v.q); }
                     __device__ __forceinline__ f32x4 passthrough(const PQ& v) const { return v.q; }
-                };
-                float part = tower_mlp_part<L3>(s_img, lane, X1TileLds{qrow, s_p + uu * H1 + 4 * h});
-                if constexpr (G > 0) {
-                    const float* grow = s_g + (g * 32 + j) * GS + h * (G / 2);
+                    const float* grow;     // this pair's GMF item row half in LDS
+                    const f32x4* gu;       // the user's GMF row half, predict weights folded in
+                    __device__ __forceinline__ float between() const
+                    {
+                        float part = 0.f;
+                        if constexpr (G > 0) {
 #pragma unroll
-                    for (int c = 0; c < G / 8; ++c) {
-                        const f32x4 gi = *reinterpret_cast<const f32x4*>(grow + 4 * c);
-                        part = fmaf(gu[c].x, gi.x, part);
-                        part = fmaf(gu[c].y, gi.y, part);
-                        part = fmaf(gu[c].z, gi.z, part);
-                        part = fmaf(gu[c].w, gi.w, part);
+                            for (int c = 0; c < G / 8; ++c) {
+                                const f32x4 gi = *reinterpret_cast<const f32x4*>(grow + 4 * c);
+                                part = fmaf(gu[c].x, gi.x, part);
+                                part = fmaf(gu[c].y, gi.y, part);
+                                part = fmaf(gu[c].z, gi.z, part);
+                                part = fmaf(gu[c].w, gi.w, part);
+                            }
+                        }
+                        return part;
                     }
-                }
+                };
+                const float part = tower_mlp_part<L3>(s_img, lane, X1TileLds{qrow, s_p + uu * H1 + 4 * h, s_g + (g * 32 + j) * GS + h * (G / 2), gu});
                 const float sc = epilogue(part + __shfl_xor(part, 32) + a.bp, a.act, a.lo, a.hi);
                 if (g == 0) held[0] = sc;
                 else held[1] = sc;
@@ -656,6 +674,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_kernel(Pair
             __device__ __forceinline__ f32x4 raw(int q) const { return *reinterpret_cast<const f32x4*>(xrow + 8 * (q & 7)); }
             __device__ __forceinline__ f32x4 finish(int, f32x4 v) const { return v; }
             __device__ __forceinline__ f32x4 passthrough(f32x4 v) const { return v; }
+            __device__ __forceinline__ float between() const { return 0.f; }
         };
         float part = tower_mlp_part<L3>(s_img, lane, X1Pair{a, xrow, s_x, ps, qs, nu2, ni2, lane, more});
         if constexpr (G > 0) {
