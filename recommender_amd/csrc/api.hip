@@ -462,9 +462,10 @@ static const int64_t kTopkExtraRows = 8192;               // bound of rows*split
 // select reads rows as float4 (N = 3533 rows would otherwise start at odd 4-byte offsets)
 static int64_t score_ld(int64_t N) { return (N + 31) / 32 * 32; }
 
-// Whole user blocks per chunk: the tile kernels work on blocks of 24 (NeuMF shapes) or 16 (Hybrid head) users, and a chunk that
-// ends inside a block leaves that block's waves half idle in EVERY chunk (1,024 users x 1M items went in chunks of 268 = 11
-// blocks + 4 users: 46 block passes instead of 43; in chunks of 240 the step measured 158.1 -> 157.6 ms).
+// Whole user blocks per chunk: the exact tile kernels work on blocks of 24 users (12 waves x 2), the split-mode kernel on 32
+// (8 waves x 4), and a chunk that ends inside a block leaves part of that block's waves idle in EVERY chunk (1,024 users x 1M
+// items went in chunks of 268 = 11 blocks + 4 users: 46 block passes instead of 43; in chunks of 240 the step measured
+// 158.1 -> 157.6 ms).  Multiples of 48 are whole blocks of 24 and whole wave rounds (8 users) of the split kernel.
 static int64_t whole_blocks(int64_t c) { return c >= 48 ? c - c % 48 : c; }
 
 static int64_t default_chunk(int64_t U, int64_t N)

@@ -61,6 +61,10 @@ constexpr int IMG_B3 = IMG_B2 + 64;           // [rq(4)][h(2)][4]
 constexpr int IMG_WPM = IMG_B3 + 32;          // predict weights, MLP half, in accumulator order (32 or 64)
 constexpr int IMG_WPG = IMG_WPM + 64;         // predict weights, GMF half [G]
 constexpr int IMG_SIZE = IMG_WPG + 64;        // 10464 floats = 41,856 B
+// The copy of the image in LDS leaves the layer-3 weights out for a tower without a third layer (the Hybrid head): 8 KB that
+// let its tile kernel hold 24 users' P rows and run three waves per SIMD like the NeuMF shapes.
+template <bool L3> constexpr int lds_img(int off) { return (L3 || off < IMG_W3) ? off : off - (IMG_B2 - IMG_W3); }
+template <bool L3> constexpr int LDS_IMG_SIZE = lds_img<L3>(IMG_SIZE);   // 10464 / 8416 floats
 
 // internal launchers (defined in the .hip files, called from api.hip)
 struct TowerImage;  // opaque here

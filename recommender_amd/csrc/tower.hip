@@ -90,11 +90,11 @@ __device__ __forceinline__ float tower_mlp_part(const float* s_img, int lane, X1
 {
     const int h = lane >> 5;
     // A wave inside the MFMA body outranks its SIMD's other waves while they stage tiles, claim work or keep lists: same-box A/B
-    // (RECO_HIP_LIB variants) cfg2 tile kernel -0.4 %, cfg5 -0.7 %, 11.5 M-pair list -1.6 %; the 8-wave Hybrid head shape lost
-    // 0.4 % with it and stays at the default priority.
-    if constexpr (L3) __builtin_amdgcn_s_setprio(1);
-    f32x16 acc0 = bias16(s_img + IMG_B2, h);
-    f32x16 acc1 = bias16(s_img + IMG_B2 + 32, h);
+    // (RECO_HIP_LIB variants) cfg2 tile kernel -0.4 %, cfg5 -0.7 %, 11.5 M-pair list -1.6 %, Hybrid head tile kernel -0.9 %
+    // (at three waves per SIMD; with two it lost 0.4 %).
+    __builtin_amdgcn_s_setprio(1);
+    f32x16 acc0 = bias16(s_img + lds_img<L3>(IMG_B2), h);
+    f32x16 acc1 = bias16(s_img + lds_img<L3>(IMG_B2) + 32, h);
     const f32x4* w2 = reinterpret_cast<const f32x4*>(s_img + IMG_W2) + lane;
     // software-pipelined by one quad: the LDS reads (and the add+ReLU) of quad q+1 are issued ahead of
     // the 8 MFMAs of quad q, so no MFMA waits on an LDS round trip
@@ -140,7 +140,7 @@ __device__ __forceinline__ float tower_mlp_part(const float* s_img, int lane, X1
     return acc0[0] + acc1[0];
 #endif
     if constexpr (L3) {
-        f32x16 acc3 = bias16(s_img + IMG_B3, h);
+        f32x16 acc3 = bias16(s_img + lds_img<L3>(IMG_B3), h);
         const f32x4* w3 = reinterpret_cast<const f32x4*>(s_img + IMG_W3) + lane;
         f32x4 a = w3[0];
 #pragma unroll
@@ -164,16 +164,18 @@ __device__ __forceinline__ float tower_mlp_part(const float* s_img, int lane, X1
             a = an;
         }
         __builtin_amdgcn_s_setprio(0);
-        part = dot16_relu(acc3, s_img + IMG_WPM, h, part);
+        part = dot16_relu(acc3, s_img + lds_img<L3>(IMG_WPM), h, part);
     } else {
-        part = dot16_relu(acc0, s_img + IMG_WPM, h, part);
-        part = dot16_relu(acc1, s_img + IMG_WPM + 32, h, part);
+        __builtin_amdgcn_s_setprio(0);
+        part = dot16_relu(acc0, s_img + lds_img<L3>(IMG_WPM), h, part);
+        part = dot16_relu(acc1, s_img + lds_img<L3>(IMG_WPM) + 32, h, part);
     }
     return part;
 }
 
-// THREADS x TUBX: 768 threads x 24 users per tile (3 waves per SIMD at <= 170 VGPRs) for the NeuMF shapes, 512 x 16 for the
-// Hybrid head, whose 64-wide GMF item tile leaves LDS room for 16 P rows only.
+// THREADS x TUBX: 768 threads x 24 users per tile (3 waves per SIMD at <= 168 VGPRs) for every shape.  The Hybrid head's 64-wide
+// GMF item tile fits beside 24 P rows because the LDS copy of the weight image leaves the (absent) third layer out
+// (lds_img<L3>, reco_common.h): 512 x 16 -> 768 x 24 took its tile kernel from 2.905 to 2.80 ms.
 template <int G, bool L3, int THREADS, int TUBX>
 __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(TileArgs a)
 {
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
     constexpr int BUF = TI * QS + (G > 0 ? TI * GS : 0);      // floats per item-side buffer
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_img = smem;
-    float* s_buf = smem + IMG_SIZE;
+    float* s_buf = smem + LDS_IMG_SIZE<L3>;
     // P rows of the tile's users: staged in LDS with the item side and read per quad by a broadcast ds_read_b128 (in 64 VGPRs
     // they cost a wave per SIMD and a global reload at every user switch)
     constexpr int NP = (TUB * (H1 / 4) + TILE_THREADS - 1) / TILE_THREADS;   // float4 of P per thread (2; 1 at 768 x 24)
@@ -198,7 +200,8 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
     const int64_t tiles = tiles_n * ((a.U + TUB - 1) / TUB);
 
     for (int i = tid; i < IMG_SIZE / 4; i += TILE_THREADS)
-        reinterpret_cast<f32x4*>(s_img)[i] = reinterpret_cast<const f32x4*>(a.img)[i];
+        if (L3 || i < IMG_W3 / 4 || i >= IMG_B2 / 4)
+            reinterpret_cast<f32x4*>(s_img)[lds_img<L3>(4 * i) / 4] = reinterpret_cast<const f32x4*>(a.img)[i];
 
     f32x4 pst[NP];
     auto p_stage_load = [&](int64_t t) {
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
                 const int64_t uid = clamp_id(a.users ? a.users[u] : a.user_base + u, a.n_users,
                                              (lane == 0 && n0 == 0) ? a.oob : nullptr);
                 const f32x4* gr = reinterpret_cast<const f32x4*>(a.EUg + uid * G + h * (G / 2));
-                const float* wpg = s_img + IMG_WPG + h * (G / 2);
+                const float* wpg = s_img + lds_img<L3>(IMG_WPG) + h * (G / 2);
 #pragma unroll
                 for (int c = 0; c < G / 8; ++c)   // fold the predict weights into the user row once per user
                     gu[c] = gr[c] * *reinterpret_cast<const f32x4*>(wpg + 4 * c);
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_topk_kernel
     constexpr int BUF = TI * QS + (G > 0 ? TI * GS : 0);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_img = smem;
-    float* s_buf = smem + IMG_SIZE;
+    float* s_buf = smem + LDS_IMG_SIZE<L3>;
     constexpr int NP = (TUB * (H1 / 4) + TILE_THREADS - 1) / TILE_THREADS;
     // The workgroup stays with one user block for many tiles, so the block's P rows are staged ONCE per block (single buffer,
     // an extra barrier at the switch) and the space of the second buffer holds the pending-candidate rings of the block's users.
@@ -365,7 +368,8 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_topk_kernel
     const unsigned blocks_u = (unsigned)((a.U + TUB - 1) / TUB);
 
     for (int i = tid; i < IMG_SIZE / 4; i += TILE_THREADS)
-        reinterpret_cast<f32x4*>(s_img)[i] = reinterpret_cast<const f32x4*>(a.img)[i];
+        if (L3 || i < IMG_W3 / 4 || i >= IMG_B2 / 4)
+            reinterpret_cast<f32x4*>(s_img)[lds_img<L3>(4 * i) / 4] = reinterpret_cast<const f32x4*>(a.img)[i];
 
     // ---- hand-out (wave 0; every value below is wave-uniform): the tile fetched last belongs to (q_blk, q_v) ----
     constexpr int LIST_SHIFT = 10;                             // published as block << 10 | visitor slot
@@ -519,7 +523,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_topk_kernel
             if constexpr (G > 0) {
                 const int64_t uid = clamp_id(a.users ? a.users[u] : a.user_base + u, a.n_users, (lane == 0 && n0 == 0) ? a.oob : nullptr);
                 const f32x4* gr = reinterpret_cast<const f32x4*>(a.EUg + uid * G + h * (G / 2));
-                const float* wpg = s_img + IMG_WPG + h * (G / 2);
+                const float* wpg = s_img + lds_img<L3>(IMG_WPG) + h * (G / 2);
 #pragma unroll
                 for (int c = 0; c < G / 8; ++c) gu[c] = gr[c] * *reinterpret_cast<const f32x4*>(wpg + 4 * c);
             }
@@ -615,11 +619,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_kernel(Pair
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
-    float* s_x = smem + IMG_SIZE + wave * WAVE_FLOATS;   // [32][HS]  relu(P+Q), one K half of this wave's pairs
+    float* s_x = smem + LDS_IMG_SIZE<L3> + wave * WAVE_FLOATS;   // [32][HS]  relu(P+Q), one K half of this wave's pairs
     float* s_gp = s_x + 32 * HS;                          // [32][GS]  gmf products
 
     for (int i = tid; i < IMG_SIZE / 4; i += 64 * WAVES)
-        reinterpret_cast<f32x4*>(s_img)[i] = reinterpret_cast<const f32x4*>(a.img)[i];
+        if (L3 || i < IMG_W3 / 4 || i >= IMG_B2 / 4)
+            reinterpret_cast<f32x4*>(s_img)[lds_img<L3>(4 * i) / 4] = reinterpret_cast<const f32x4*>(a.img)[i];
     __syncthreads();
 
     const int64_t ngroups = (a.B + 31) / 32;
@@ -679,7 +684,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_kernel(Pair
         float part = tower_mlp_part<L3>(s_img, lane, X1Pair{a, xrow, s_x, ps, qs, nu2, ni2, lane, more});
         if constexpr (G > 0) {
             const float* grow = s_gp + j * GS + h * (G / 2);
-            const float* wpg = s_img + IMG_WPG + h * (G / 2);
+            const float* wpg = s_img + lds_img<L3>(IMG_WPG) + h * (G / 2);
 #pragma unroll
             for (int c = 0; c < G / 8; ++c) {
                 const f32x4 gp = *reinterpret_cast<const f32x4*>(grow + 4 * c);
@@ -799,8 +804,8 @@ int launch_tile_t(const TileArgs& a, hipStream_t s)
 {
     // with the P rows in LDS the kernel needs 143 VGPRs: three waves per SIMD (768 threads, 24 users per tile, LDS 152 KB)
     // measured 3.35 -> 3.32 ms; the Hybrid head (64-wide GMF tile) has LDS room for 16 users per tile: 512 threads
-    constexpr int THREADS = G <= 32 ? 768 : 512, TUBX = G <= 32 ? 24 : 16;
-    constexpr size_t lds = (size_t)(IMG_SIZE + 2 * (TI * QS + (G > 0 ? TI * (G + 4) : 0)) + 2 * TUBX * H1) * sizeof(float);
+    constexpr int THREADS = 768, TUBX = 24;
+    constexpr size_t lds = (size_t)(LDS_IMG_SIZE<L3> + 2 * (TI * QS + (G > 0 ? TI * (G + 4) : 0)) + 2 * TUBX * H1) * sizeof(float);
     static_assert(lds <= 160 * 1024, "tile kernel LDS budget");
     static bool attr[RECO_MAX_DEVICES] = {};
     if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&tower_tile_kernel<G, L3, THREADS, TUBX>), lds, attr)) return rc;
@@ -821,9 +826,9 @@ int launch_tile_t(const TileArgs& a, hipStream_t s)
 template <int G, bool L3, int SLOTS>
 int launch_tile_topk_t(const TileArgs& a, const TopkFuse& f, hipStream_t s)
 {
-    constexpr int THREADS = G <= 32 ? 768 : 512, TUBX = G <= 32 ? 24 : 16;     // as launch_tile_t
+    constexpr int THREADS = 768, TUBX = 24;     // as launch_tile_t
     // image | two item-side buffers | one block of P rows | one 64-key ring per user (the same total as launch_tile_t's)
-    constexpr size_t lds = (size_t)(IMG_SIZE + 2 * (TI * QS + (G > 0 ? TI * (G + 4) : 0)) + TUBX * H1) * sizeof(float) +
+    constexpr size_t lds = (size_t)(LDS_IMG_SIZE<L3> + 2 * (TI * QS + (G > 0 ? TI * (G + 4) : 0)) + TUBX * H1) * sizeof(float) +
                            (size_t)TUBX * 64 * sizeof(unsigned long long);
     static_assert(lds <= 160 * 1024, "tile kernel LDS budget");
     static bool attr[RECO_MAX_DEVICES] = {};
@@ -847,7 +852,7 @@ int launch_pairs_tb(const PairArgs& a, hipStream_t s)
 {
     // 8 waves per workgroup when their half-row staging areas fit next to the image (G <= 32: 148 KB), else 4
     constexpr int WAVES = G <= 32 ? 8 : 4;
-    constexpr size_t lds = (size_t)(IMG_SIZE + WAVES * (32 * HS + (G > 0 ? 32 * (G + 4) : 0))) * sizeof(float);
+    constexpr size_t lds = (size_t)(LDS_IMG_SIZE<L3> + WAVES * (32 * HS + (G > 0 ? 32 * (G + 4) : 0))) * sizeof(float);
     static_assert(lds <= 160 * 1024, "pair kernel LDS budget");
     static bool attr[RECO_MAX_DEVICES] = {};
     if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&tower_pairs_kernel<G, L3, WAVES, BIG>), lds, attr)) return rc;
@@ -938,7 +943,7 @@ int gmf_launch_tile(const float* EUg, const float* EIg, const float* wp, const i
 }
 
 // ---- fused score + top-k (tower_tile_topk_kernel) ----
-int tower_tile_users_per_block(int G) { return G <= 32 ? 24 : 16; }
+int tower_tile_users_per_block(int G) { (void)G; return 24; }
 
 // counters: [fresh | pad to 64 words | next_tile[blocks] | visits[blocks]], zeroed by the caller together with `partial`
 size_t tower_topk_counter_bytes(int G, int64_t U)
