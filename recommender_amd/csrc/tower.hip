@@ -850,7 +850,8 @@ int launch_tile_topk_t(const TileArgs& a, const TopkFuse& f, hipStream_t s)
 template <int G, bool L3, bool BIG>
 int launch_pairs_tb(const PairArgs& a, hipStream_t s)
 {
-    // 8 waves per workgroup when their half-row staging areas fit next to the image (G <= 32: 148 KB), else 4
+    // 8 waves per workgroup when their half-row staging areas fit next to the image (G <= 32: 148 KB), else 4 (six waves of the
+    // Hybrid shape fit since its LDS image dropped layer 3, but measured slower: 1M pair rows 1.11 -> 1.19 ms)
     constexpr int WAVES = G <= 32 ? 8 : 4;
     constexpr size_t lds = (size_t)(LDS_IMG_SIZE<L3> + WAVES * (32 * HS + (G > 0 ? 32 * (G + 4) : 0))) * sizeof(float);
     static_assert(lds <= 160 * 1024, "pair kernel LDS budget");

@@ -173,6 +173,14 @@ def bench_tower():
     zu = h.user_autorec.encode(R); zi = h.item_autorec.encode(R.t().contiguous())
     ms = timeit(lambda: h.ncf.score_matrix(zu, zi), reps=10)
     emit("tower_tile_kernel<64,false> (+projections)", "6040 x 3706", ms, "mfma", 6040 * 3706 * HYBRID_EXEC, "16,832 FLOP/pair executed", "", 6040 * 3706 * HYBRID_ALG)
+    Bp = 1 << 20                                  # Hybrid forward over pair rows (every pair brings its latents): score_rows
+    gp = torch.Generator().manual_seed(2)
+    zub = zu[torch.randint(0, 6040, (Bp,), generator=gp).to(dev)].contiguous()
+    zib = zi[torch.randint(0, 3706, (Bp,), generator=gp).to(dev)].contiguous()
+    th = h.ncf._tower(dev)
+    ms = timeit(lambda: th.score_rows(zub, zib, zub, zib), reps=10)
+    emit("tower_pairs_kernel<64,false> + per-pair layer-1 projections (Hybrid forward, score_rows)", "B=%d pair rows" % Bp, ms, "mfma",
+         Bp * HYBRID_ALG, "49,472 FLOP/pair, all executed (nothing to factorise: every pair has its own rows)", "pairs/s = %.3g" % (Bp / ms * 1e3))
     ops.set_tower_precision("bf16x3")
     ms = timeit(lambda: h.ncf.score_matrix(zu, zi), reps=10)
     emit("tower_tile_split_kernel<64,false> (bf16x3, +projections)", "6040 x 3706", ms, "mfma", 6040 * 3706 * HYBRID_EXEC,
