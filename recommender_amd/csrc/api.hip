@@ -752,9 +752,9 @@ extern "C" int reco_tower_score_topk_noalloc(reco_tower_t* t, const int64_t* use
         ptr = g_scratch_ptr[t->device];
     }
     RECO_REQUIRE(ptr != nullptr, "score_topk_noalloc: no scratch address recorded for device %d", t->device);
-    // the array keeps the previous call's bytes: the only word that must start at zero is the tile queue counter, which
-    // score_matrix_impl clears (hipMemsetAsync on `stream`) before every tile-kernel launch; every other region is
-    // written before it is read within the call
+    // the array keeps the previous call's bytes.  What must start at zero is cleared on `stream` before every launch that
+    // reads it: the tile queue counter (score_matrix_impl), or -- when the call takes the fused form -- the hand-out counters
+    // and the partial lists (score_topk_fused); every other region is written before it is read within the call
     return score_topk_impl(t, users, user_base, U, cands, N, k, exclude, ld_ex, out_ids, out_scores, oob, ptr,
                            (size_t)RECO_NOALLOC_SCRATCH_BYTES, (hipStream_t)stream, "score_topk_noalloc");
 }

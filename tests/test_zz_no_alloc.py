@@ -86,6 +86,20 @@ def test_noalloc_topk_equals_the_workspace_form_on_two_calls_in_a_row_second_sma
     assert (ids_d == ref_ids).mean() > 0.99
 
 
+def test_noalloc_topk_in_the_fused_form_when_the_score_rows_need_several_user_chunks():
+    """6,100 users x 45,000 items = 1.1 GB of score rows: reco_tower_score_topk (and the no-alloc form with it) scores and selects
+    in one kernel per user chunk; inside 32 MiB of scratch the chunks are a few hundred users, in the caller's workspace one."""
+    _, tower = _tower(6100, 45000, 2)
+    (ids_a, vals_a), (ids_b, vals_b) = _both(tower, None, 0, 6100, None, 45000, 20, None)
+    assert np.array_equal(ids_a, ids_b) and np.array_equal(vals_a.view(np.uint32), vals_b.view(np.uint32))
+    assert (ids_b >= 0).all() and (ids_b < 45000).all()
+    # a second, smaller call right behind it (the scratch still holds the first call's lists and counters)
+    users = torch.arange(100, 300, device=tower.device)
+    (ids_c, vals_c), (ids_d, vals_d) = _both(tower, users, 0, 200, None, 45000, 5, None)
+    assert np.array_equal(ids_c, ids_d) and np.array_equal(vals_c.view(np.uint32), vals_d.view(np.uint32))
+    assert np.array_equal(ids_d, ids_b[100:300, :5])
+
+
 def test_noalloc_topk_rejects_what_does_not_fit_and_launches_nothing():
     from recommender_amd import _lib
     L = _lib.lib()
