@@ -104,7 +104,7 @@ __device__ __forceinline__ f32x4 load_k4(const float* row, int64_t k, int64_t K)
 // K is consumed in BK = 32 tiles through a double-buffered LDS image: the global loads of tile t+1 are issued before
 // the MFMAs of tile t and written to the other buffer after them -- one barrier per tile, no branch in the steady state
 // (rows past M / N are clamped to the last row and discarded at the store; only the ragged last K tile is guarded).
-template <int BM, int BN, int VEC, bool AT, bool SPLIT>
+template <int BM, int BN, int VEC, bool AT, bool SPLIT, bool ONE>
 __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
 {
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -116,7 +116,11 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
     // split form and transposed A: ONE LDS image, so more workgroups share a CU and one's staging (global loads, operand
     // splitting / transposing, LDS writes) overlaps the others' MFMAs (measured: transposed encoder 0.30 -> 0.26 ms, split
     // 4096^3 0.93 -> 0.76 ms); the plain exact form double-buffers inside the workgroup (4096^3: 1.09 vs 1.21 ms single)
-    constexpr int NBUF = (SPLIT || AT) ? 1 : 2;
+    // ONE: the plain exact form with a short K (<= 768 per slice, e.g. the AutoRec decoder's 500): a tile is then mostly
+    // prologue and epilogue, and four single-buffered workgroups per CU overlap those better than two double-buffered ones
+    // (decoder 0.250 -> 0.243 ms, the Hybrid encoders' six launches 0.357 -> 0.308 ms; 864-wide slices of the AutoRec encoder's
+    // split K were 1.6 % slower this way, and at K = 4096 the double buffer wins 1.09 vs 1.21 ms)
+    constexpr int NBUF = (SPLIT || AT || ONE) ? 1 : 2;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -374,16 +378,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(LinArgs a)
     }
 }
 
+template <int BM, int BN, int VEC, bool AT, bool SPLIT, bool ONE>
+int launch_k(const LinArgs& a, hipStream_t s)
+{
+    constexpr size_t lds = SPLIT ? (size_t)3 * (BM + BN) * LSB * 2 : (size_t)((AT || ONE) ? 1 : 2) * (BM + BN) * LS * sizeof(float);
+    static bool attr[RECO_MAX_DEVICES] = {};
+    if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&linear_kernel<BM, BN, VEC, AT, SPLIT, ONE>), lds, attr)) return rc;
+    const int64_t blocks = ceil_div64(a.M, BM) * ceil_div64(a.N, BN) * a.splits;
+    RECO_REQUIRE(blocks < (1ll << 31), "linear grid too large");
+    hipLaunchKernelGGL((linear_kernel<BM, BN, VEC, AT, SPLIT, ONE>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    RECO_CHECK_LAUNCH();
+    return RECO_OK;
+}
+
 template <int BM, int BN, int VEC, bool AT, bool SPLIT>
 int launch_v(const LinArgs& a, hipStream_t s)
 {
-    constexpr size_t lds = SPLIT ? (size_t)3 * (BM + BN) * LSB * 2 : (size_t)(AT ? 1 : 2) * (BM + BN) * LS * sizeof(float);
-    static bool attr[RECO_MAX_DEVICES] = {};
-    if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&linear_kernel<BM, BN, VEC, AT, SPLIT>), lds, attr)) return rc;
-    const int64_t blocks = ceil_div64(a.M, BM) * ceil_div64(a.N, BN) * a.splits;
-    RECO_REQUIRE(blocks < (1ll << 31), "linear grid too large");
-    hipLaunchKernelGGL((linear_kernel<BM, BN, VEC, AT, SPLIT>), dim3((unsigned)blocks), dim3(256), lds, s, a);
-    RECO_CHECK_LAUNCH();
+    int rc;
+    if constexpr (!AT && !SPLIT) rc = a.k_per_split <= 768 ? launch_k<BM, BN, VEC, AT, SPLIT, true>(a, s) : launch_k<BM, BN, VEC, AT, SPLIT, false>(a, s);
+    else rc = launch_k<BM, BN, VEC, AT, SPLIT, false>(a, s);
+    if (rc) return rc;
     if (a.splits > 1) {
         const int64_t rb = ceil_div64(a.M * a.N, 256);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(rb < 4096 ? rb : 4096)), dim3(256), 0, s, a);
