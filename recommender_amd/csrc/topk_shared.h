@@ -36,10 +36,28 @@ __device__ __forceinline__ u64 bcast(u64 v, int src)
     return ((u64)hi << 32) | lo;
 }
 
+// v of lane (l ^ mask).  Partners inside a row of 16 lanes come through DPP (a VALU move, a few cycles) instead of an LDS
+// cross-lane round trip: quad_perm for 1 and 2, a rotation by 8 for 8, and for 4 a shift left into banks 0/2 plus a shift
+// right into banks 1/3 (row_shl:n = lane i reads lane i + n, row_shr:n = lane i reads lane i - n; bank b = lanes 4b..4b+3).
+__device__ __forceinline__ uint32_t shfl_xor32(uint32_t v, int mask)
+{
+    const int x = (int)v;
+    switch (mask) {
+        case 1: return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);     // quad_perm [1,0,3,2]
+        case 2: return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false);     // quad_perm [2,3,0,1]
+        case 4: {
+            const int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);           // row_shl:4 -> banks 0, 2
+            return (uint32_t)__builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);        // row_shr:4 -> banks 1, 3
+        }
+        case 8: return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false);     // row_ror:8
+        default: return (uint32_t)__shfl_xor(x, mask);
+    }
+}
+
 __device__ __forceinline__ u64 shfl_xor64(u64 v, int mask)
 {
-    const uint32_t lo = __shfl_xor((uint32_t)v, mask);
-    const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), mask);
+    const uint32_t lo = shfl_xor32((uint32_t)v, mask);
+    const uint32_t hi = shfl_xor32((uint32_t)(v >> 32), mask);
     return ((u64)hi << 32) | lo;
 }
 
