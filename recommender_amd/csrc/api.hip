@@ -15,7 +15,8 @@ int tower_launch_tile(int G, int has_l3, const float* img, const float* P, const
                       const float* EUg, const float* EIg, const int64_t* users, const int64_t* cands,
                       int64_t user_base, int64_t n_users, int64_t n_items, int64_t U, int64_t N,
                       float* out, int64_t ld_out, float bp, int act, float lo, float hi, int32_t* oob,
-                      unsigned int* next_tile, hipStream_t s);
+                      unsigned int* next_tile, const float* pmax, const float* qmax, hipStream_t s);
+int tower_launch_posmax(const float* x, int64_t n, unsigned int* out, hipStream_t s);
 int tower_launch_pairs(int G, int has_l3, const float* img, const float* P, const float* Q,
                        const float* EUg, const float* EIg, const int64_t* user, const int64_t* item,
                        int64_t n_users, int64_t n_items, int64_t B, float* out, float bp, int act,
@@ -38,7 +39,8 @@ int tower_launch_tile_topk(int G, int has_l3, const float* img, const float* P, 
                            const float* EUg, const float* EIg, const int64_t* users, const int64_t* cands,
                            int64_t user_base, int64_t n_users, int64_t n_items, int64_t U, int64_t N,
                            float bp, int act, float lo, float hi, int32_t* oob,
-                           int k, int v_max, unsigned int* counters, unsigned long long* partial, hipStream_t s);
+                           int k, int v_max, unsigned int* counters, unsigned long long* partial,
+                           const float* pmax, const float* qmax, hipStream_t s);
 int gmf_launch_pairs(const float* EUg, const float* EIg, const float* wp, const int64_t* user,
                      const int64_t* item, int64_t n_users, int64_t n_items, int64_t B, int G, float* out,
                      float bp, int act, float lo, float hi, int32_t* oob, hipStream_t s);
@@ -214,6 +216,7 @@ struct reco_tower {
     void* img_split;  // bf16x3 image (RECO_PREC_SPLIT_BF16X3 only)
     float* P;         // [n_users,128] layer-1 user projection (+ b1)
     float* Q;         // [n_items,128] layer-1 item projection
+    unsigned int* qmax;  // device word: largest finite positive element of Q (a float's bits), for layer1_scale() in the tile kernels
     int device;
 };
 
@@ -263,6 +266,7 @@ extern "C" void reco_tower_destroy(reco_tower_t* t)
     (void)hipFree(t->img_split);
     (void)hipFree(t->P);
     (void)hipFree(t->Q);
+    (void)hipFree(t->qmax);
     delete t;
 }
 
@@ -320,6 +324,7 @@ extern "C" int reco_tower_create(const reco_tower_desc_t* d, void* stream, reco_
     if (e == hipSuccess && split) e = hipMalloc(&t->img_split, tower_split_image_bytes(t->has_l3));
     if (e == hipSuccess && t->mfma && tables) e = hipMalloc(&t->P, (size_t)d->n_users * H1 * sizeof(float));
     if (e == hipSuccess && t->mfma && tables) e = hipMalloc(&t->Q, (size_t)d->n_items * H1 * sizeof(float));
+    if (e == hipSuccess && t->mfma && tables) e = hipMalloc(&t->qmax, 256);
     if (e == hipSuccess) e = hipMemcpyAsync(&t->bp, d->b_predict, sizeof(float), hipMemcpyDeviceToHost, s);
     if (e != hipSuccess) {
         reco_set_error("tower_create: %s", hipGetErrorString(e));
@@ -333,6 +338,11 @@ extern "C" int reco_tower_create(const reco_tower_desc_t* d, void* stream, reco_
             rc = tower_pack_split_image(d->W[1], t->has_l3 ? d->W[2] : nullptr, t->has_l3, t->img, t->img_split, s);
         if (!rc && tables)
             rc = tower_project(t, d->user_mlp, nullptr, 0, d->n_users, d->item_mlp, nullptr, 0, d->n_items, t->P, t->Q, nullptr, s);
+        if (!rc && tables) {
+            e = hipMemsetAsync(t->qmax, 0, 256, s);
+            if (e != hipSuccess) { reco_set_error("tower_create: %s", hipGetErrorString(e)); rc = RECO_EHIP; }
+            else rc = tower_launch_posmax(t->Q, d->n_items * H1, t->qmax, s);
+        }
     }
     if (!rc) {
         e = hipStreamSynchronize(s);
@@ -393,14 +403,18 @@ extern "C" int reco_tower_score_rows(reco_tower_t* t, const float* u_gmf, const 
 }
 
 // ---- matrix / top-k forms ----------------------------------------------------------------------
-static const size_t kQueueBytes = 256;   // tile work-queue counter at the head of the call workspace
+// Head of every call workspace (256 bytes): word 0 = tile work-queue counter, word 16 = largest finite positive element of the
+// P rows of the launch, word 32 = the same of the Q rows of the call (float bit patterns, posmax_kernel; tower_shared.h
+// layer1_scale()).  Words 0 and 16 are cleared per launch, word 32 once per call.
+static const size_t kQueueBytes = 256;
+static const int kPmaxWord = 16, kQmaxWord = 32;
 static size_t proj_bytes(int64_t rows) { return align_up((size_t)(rows > 0 ? rows : 0) * H1 * sizeof(float), 256); }
 
 extern "C" size_t reco_tower_matrix_workspace_bytes(int64_t U, int64_t N) { return kQueueBytes + proj_bytes(U) + proj_bytes(N); }
 
 static int score_matrix_impl(reco_tower* t, const int64_t* users, int64_t user_base, int64_t U,
-                             const int64_t* cands, int64_t N, const float* Qready, float* out, int64_t ld_out,
-                             float* P, float* Q, unsigned int* queue, int32_t* oob, hipStream_t s)
+                             const int64_t* cands, int64_t N, const float* Qready, const unsigned int* qmax_ready,
+                             float* out, int64_t ld_out, float* P, float* Q, unsigned int* queue, int32_t* oob, hipStream_t s)
 {
     const reco_tower_desc_t& d = t->d;
     if (!t->mfma)
@@ -410,14 +424,21 @@ static int score_matrix_impl(reco_tower* t, const int64_t* users, int64_t user_b
     const float* urows = users ? d.user_mlp : d.user_mlp + user_base * d.dm;
     int rc = tower_project(t, urows, users, d.n_users, U, d.item_mlp, cands, d.n_items, Qready ? 0 : N, P, Q, oob, s);
     if (rc) return rc;
-    if (queue) RECO_CHECK_HIP(hipMemsetAsync(queue, 0, sizeof(unsigned int), s));
+    RECO_REQUIRE(queue && (!Qready || qmax_ready), "score_matrix: internal: workspace head / item-side maximum missing");
+    RECO_CHECK_HIP(hipMemsetAsync(queue, 0, (Qready ? kQmaxWord : kQmaxWord + 1) * sizeof(unsigned int), s));
+    const unsigned int* qmax = Qready ? qmax_ready : queue + kQmaxWord;
+    if (!t->img_split) {             // the exact tile kernels scale layer 1 by these (the split mode does not)
+        if ((rc = tower_launch_posmax(P, U * H1, queue + kPmaxWord, s))) return rc;
+        if (!Qready && (rc = tower_launch_posmax(Q, N * H1, queue + kQmaxWord, s))) return rc;
+    }
     ProfScope prof(s);
     if (t->img_split)
         return tower_launch_tile_split(t->G, t->has_l3, t->img_split, P, Qready ? Qready : Q, d.user_gmf, d.item_gmf, users,
                                        cands, user_base, d.n_users, d.n_items, U, N, out, ld_out, t->bp, d.act, d.lo, d.hi,
                                        oob, queue, s);
     return tower_launch_tile(t->G, t->has_l3, t->img, P, Qready ? Qready : Q, d.user_gmf, d.item_gmf, users, cands,
-                             user_base, d.n_users, d.n_items, U, N, out, ld_out, t->bp, d.act, d.lo, d.hi, oob, queue, s);
+                             user_base, d.n_users, d.n_items, U, N, out, ld_out, t->bp, d.act, d.lo, d.hi, oob, queue,
+                             reinterpret_cast<const float*>(queue + kPmaxWord), reinterpret_cast<const float*>(qmax), s);
 }
 
 static int check_ranges(const reco_tower* t, const int64_t* users, int64_t user_base, int64_t U, const int64_t* cands,
@@ -450,7 +471,7 @@ extern "C" int reco_tower_score_matrix(reco_tower_t* t, const int64_t* users, in
         P = reinterpret_cast<float*>(static_cast<char*>(ws) + kQueueBytes);
         Q = reinterpret_cast<float*>(static_cast<char*>(ws) + kQueueBytes + proj_bytes(U));
     }
-    return score_matrix_impl(t, users, user_base, U, cands, N, nullptr, out, ld_out, P, Q, queue, oob, (hipStream_t)stream);
+    return score_matrix_impl(t, users, user_base, U, cands, N, nullptr, nullptr, out, ld_out, P, Q, queue, oob, (hipStream_t)stream);
 }
 
 // user-chunk size for the fused score + top-k path
@@ -562,13 +583,21 @@ static int score_topk_fused(reco_tower_t* t, const int64_t* users, int64_t user_
     unsigned long long* partial = reinterpret_cast<unsigned long long*>(w + counter_bytes);
     const bool cached_q = !cands && N == d.n_items && U <= kServingUsers && t->Q;     // as the unfused form below
     int rc = RECO_OK;
-    if (cached_q) Q = t->Q;
-    else if ((rc = tower_project(t, nullptr, nullptr, 0, 0, d.item_mlp, cands, d.n_items, N, nullptr, Q, oob, s))) return rc;
+    unsigned int* head = static_cast<unsigned int*>(ws);       // layer-1 maxima live in the workspace head (no tile queue here)
+    const unsigned int* qmax = head + kQmaxWord;
+    if (cached_q) { Q = t->Q; qmax = t->qmax; }
+    else {
+        if ((rc = tower_project(t, nullptr, nullptr, 0, 0, d.item_mlp, cands, d.n_items, N, nullptr, Q, oob, s))) return rc;
+        RECO_CHECK_HIP(hipMemsetAsync(head + kQmaxWord, 0, sizeof(unsigned int), s));
+        if ((rc = tower_launch_posmax(Q, N * H1, head + kQmaxWord, s))) return rc;
+    }
     for (int64_t c0 = 0; c0 < U; c0 += Uc) {
         const int64_t n = U - c0 < Uc ? U - c0 : Uc;
         const int64_t* ul = users ? users + c0 : nullptr;
         const float* urows = ul ? d.user_mlp : d.user_mlp + (user_base + c0) * d.dm;
         if ((rc = tower_project(t, urows, ul, d.n_users, n, nullptr, nullptr, 0, 0, P, nullptr, oob, s))) return rc;
+        RECO_CHECK_HIP(hipMemsetAsync(head, 0, kQmaxWord * sizeof(unsigned int), s));
+        if ((rc = tower_launch_posmax(P, n * H1, head + kPmaxWord, s))) return rc;
         // hand-out counters and partial lists start at zero (a list nobody wrote reads as empty)
         int v = fuse_visitors(t->G, n, N, k);                                    // a short last chunk may take more lists per block
         if ((int64_t)v * n > list_room) v = (int)(list_room / n);
@@ -576,7 +605,8 @@ static int score_topk_fused(reco_tower_t* t, const int64_t* users, int64_t user_
         {
             ProfScope prof(s);
             rc = tower_launch_tile_topk(t->G, t->has_l3, t->img, P, Q, d.user_gmf, d.item_gmf, ul, cands, user_base + c0, d.n_users,
-                                        d.n_items, n, N, t->bp, d.act, d.lo, d.hi, oob, k, v, counters, partial, s);
+                                        d.n_items, n, N, t->bp, d.act, d.lo, d.hi, oob, k, v, counters, partial,
+                                        reinterpret_cast<const float*>(head + kPmaxWord), reinterpret_cast<const float*>(qmax), s);
         }
         if (rc) return rc;
         if ((rc = launch_topk_merge(partial, n, v, k, out_ids + c0 * k, out_scores + c0 * k, s))) return rc;
@@ -619,14 +649,19 @@ static int score_topk_impl(reco_tower_t* t, const int64_t* users, int64_t user_b
     // item-side projection once per call.  Request-sized calls over the whole catalog (a handful of users: the serving
     // path, inference_engine.py:149-166) reuse the projection of all items that the handle packed at creation instead.
     const bool cached_q = t->mfma && !cands && N == d.n_items && U <= kServingUsers && t->Q;
-    if (cached_q) Q = t->Q;
+    const unsigned int* qmax = queue ? queue + kQmaxWord : nullptr;      // the item side's layer-1 maximum, once per call
+    if (cached_q) { Q = t->Q; qmax = t->qmax; }
     else if (t->mfma) {
         rc = tower_project(t, nullptr, nullptr, 0, 0, d.item_mlp, cands, d.n_items, N, nullptr, Q, oob, s);
         if (rc) return rc;
+        if (!t->img_split) {
+            RECO_CHECK_HIP(hipMemsetAsync(queue + kQmaxWord, 0, sizeof(unsigned int), s));
+            if ((rc = tower_launch_posmax(Q, N * H1, queue + kQmaxWord, s))) return rc;
+        }
     }
     for (int64_t c0 = 0; c0 < U; c0 += Uc) {
         const int64_t n = U - c0 < Uc ? U - c0 : Uc;
-        rc = score_matrix_impl(t, users ? users + c0 : nullptr, user_base + c0, n, cands, N, Q, scores, ldN, P, Q, queue, oob, s);
+        rc = score_matrix_impl(t, users ? users + c0 : nullptr, user_base + c0, n, cands, N, Q, qmax, scores, ldN, P, Q, queue, oob, s);
         if (rc) return rc;
         rc = launch_topk_rows(scores, n, N, ldN, k, exclude ? exclude + c0 * ld_ex : nullptr, ld_ex, out_ids + c0 * k,
                               out_scores + c0 * k, tws, tws_bytes, s);

@@ -134,8 +134,11 @@ __device__ __forceinline__ float tower_mlp_part(const float* s_img, int lane, X1
         __builtin_amdgcn_sched_barrier(0);
         x = xn; a0 = a0n; a1 = a1n;
     }
-    // independent work of the caller (the GMF half of the predict layer) fills the wait for layer 2's last accumulators
-    float part = x1.between();
+    // independent work of the caller (the GMF half of the predict layer) fills the wait for layer 2's last accumulators.
+    // The two halves of the predict layer are summed separately and added at the end, in every kernel that uses this body: the
+    // tile kernels (GMF half here) and the pair-list kernel (GMF half after the call) then agree to the bit.
+    const float pre = x1.between();
+    float part = 0.f;
 #ifdef RECO_ABL_NO_L3
     return acc0[0] + acc1[0];
 #endif
@@ -170,7 +173,7 @@ __device__ __forceinline__ float tower_mlp_part(const float* s_img, int lane, X1
         part = dot16_relu(acc0, s_img + lds_img<L3>(IMG_WPM), h, part);
         part = dot16_relu(acc1, s_img + lds_img<L3>(IMG_WPM) + 32, h, part);
     }
-    return part;
+    return pre + part;
 }
 
 // THREADS x TUBX: 768 threads x 24 users per tile (3 waves per SIMD at <= 168 VGPRs) for every shape.  The Hybrid head's 64-wide
@@ -199,9 +202,8 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
     const int64_t tiles_n = (a.N + TI - 1) / TI;
     const int64_t tiles = tiles_n * ((a.U + TUB - 1) / TUB);
 
-    for (int i = tid; i < IMG_SIZE / 4; i += TILE_THREADS)
-        if (L3 || i < IMG_W3 / 4 || i >= IMG_B2 / 4)
-            reinterpret_cast<f32x4*>(s_img)[lds_img<L3>(4 * i) / 4] = reinterpret_cast<const f32x4*>(a.img)[i];
+    const Layer1Scale l1 = layer1_scale(a.pmax, a.qmax);
+    load_image_scaled<L3, TILE_THREADS>(s_img, a.img, tid, l1);
 
     f32x4 pst[NP];
     auto p_stage_load = [&](int64_t t) {
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
 #pragma unroll
         for (int s = 0; s < NP; ++s)
             if (tid + s * TILE_THREADS < TUB * (H1 / 4))
-                reinterpret_cast<f32x4*>(s_pbuf + buf * TUB * H1)[tid + s * TILE_THREADS] = pst[s];
+                reinterpret_cast<f32x4*>(s_pbuf + buf * TUB * H1)[tid + s * TILE_THREADS] = pst[s] * l1.s;
     };
 
 #ifdef RECO_DIAG_CLOCK
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
     tile_queue_fetch(a, tid, tile + gridDim.x, &s_next[0]);
     if (tile < tiles) {
         tile_stage_load<G, THREADS>(a, (tile % tiles_n) * TI, tile / tiles_n == 0, tid, st);
-        tile_stage_store<G, THREADS>(s_buf, s_buf + TI * QS, tid, st);
+        tile_stage_store<G, THREADS>(s_buf, s_buf + TI * QS, tid, st, l1.s);
         p_stage_load(tile);
         p_stage_store(0);
     }
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
                         return PQ{*reinterpret_cast<const f32x4*>(qrow + 8 * q), *reinterpret_cast<const f32x4*>(prow + 8 * q)};
                     }
                     __device__ __forceinline__ void pre(int) const {}
-                    __device__ __forceinline__ f32x4 finish(int, const PQ& v) const { return relu4(v.p + v.q); }
+                    __device__ __forceinline__ f32x4 finish(int, const PQ& v) const { return add_clamp4(v.p, v.q); }   // = s * relu(p + q)
                     __device__ __forceinline__ f32x4 passthrough(const PQ& v) const { return v.q; }
                     const float* grow;     // this pair's GMF item row half in LDS
                     const f32x4* gu;       // the user's GMF row half, predict weights folded in
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
         }
         if (next < tiles) {
             float* d_q = s_buf + ((it + 1) & 1) * BUF;
-            tile_stage_store<G, THREADS>(d_q, d_q + TI * QS, tid, st);
+            tile_stage_store<G, THREADS>(d_q, d_q + TI * QS, tid, st, l1.s);
             p_stage_store((it + 1) & 1);
         }
         __syncthreads();   // tile i fully consumed, tile i + 1 fully staged
@@ -367,9 +369,8 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_topk_kernel
     const unsigned tiles_n = (unsigned)((a.N + TI - 1) / TI);
     const unsigned blocks_u = (unsigned)((a.U + TUB - 1) / TUB);
 
-    for (int i = tid; i < IMG_SIZE / 4; i += TILE_THREADS)
-        if (L3 || i < IMG_W3 / 4 || i >= IMG_B2 / 4)
-            reinterpret_cast<f32x4*>(s_img)[lds_img<L3>(4 * i) / 4] = reinterpret_cast<const f32x4*>(a.img)[i];
+    const Layer1Scale l1 = layer1_scale(a.pmax, a.qmax);
+    load_image_scaled<L3, TILE_THREADS>(s_img, a.img, tid, l1);
 
     // ---- hand-out (wave 0; every value below is wave-uniform): the tile fetched last belongs to (q_blk, q_v) ----
     constexpr int LIST_SHIFT = 10;                             // published as block << 10 | visitor slot
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_topk_kernel
 #pragma unroll
         for (int s = 0; s < NP; ++s)
             if (tid + s * TILE_THREADS < TUB * (H1 / 4))
-                reinterpret_cast<f32x4*>(s_pbuf)[tid + s * TILE_THREADS] = pst[s];
+                reinterpret_cast<f32x4*>(s_pbuf)[tid + s * TILE_THREADS] = pst[s] * l1.s;
     };
 
     // ---- per-wave top-k state: one sorted list per owned user ----
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_topk_kernel
     unsigned cur_blkv = s_blkv[0], cur_t = s_t[0];
     if (cur_t != ~0u) {
         tile_stage_load<G, THREADS>(a, (int64_t)cur_t * TI, (cur_blkv >> LIST_SHIFT) == 0, tid, st);
-        tile_stage_store<G, THREADS>(s_buf, s_buf + TI * QS, tid, st);
+        tile_stage_store<G, THREADS>(s_buf, s_buf + TI * QS, tid, st, l1.s);
         p_stage_load(cur_blkv >> LIST_SHIFT);
         p_stage_store();
     }
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_topk_kernel
                         return PQ{*reinterpret_cast<const f32x4*>(qrow + 8 * q), *reinterpret_cast<const f32x4*>(prow + 8 * q)};
                     }
                     __device__ __forceinline__ void pre(int) const {}
-                    __device__ __forceinline__ f32x4 finish(int, const PQ& v) const { return relu4(v.p + v.q); }
+                    __device__ __forceinline__ f32x4 finish(int, const PQ& v) const { return add_clamp4(v.p, v.q); }   // = s * relu(p + q)
                     __device__ __forceinline__ f32x4 passthrough(const PQ& v) const { return v.q; }
                     const float* grow;     // this pair's GMF item row half in LDS
                     const f32x4* gu;       // the user's GMF row half, predict weights folded in
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_topk_kernel
         }
         if (nxt_t != ~0u) {
             float* d_q = s_buf + ((it + 1) & 1) * BUF;
-            tile_stage_store<G, THREADS>(d_q, d_q + TI * QS, tid, st);
+            tile_stage_store<G, THREADS>(d_q, d_q + TI * QS, tid, st, l1.s);
         }
         if (wave == 0) fetch(it & 1);                          // slot it & 1 was read as `nxt` two barriers ago
         __syncthreads();   // tile fully consumed, next tile fully staged, the tile after next published
@@ -685,15 +686,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_kernel(Pair
         if constexpr (G > 0) {
             const float* grow = s_gp + j * GS + h * (G / 2);
             const float* wpg = s_img + lds_img<L3>(IMG_WPG) + h * (G / 2);
+            float gm = 0.f;                                    // summed on its own, as in the tile kernels (tower_mlp_part)
 #pragma unroll
             for (int c = 0; c < G / 8; ++c) {
                 const f32x4 gp = *reinterpret_cast<const f32x4*>(grow + 4 * c);
                 const f32x4 w = *reinterpret_cast<const f32x4*>(wpg + 4 * c);
-                part = fmaf(gp.x, w.x, part);
-                part = fmaf(gp.y, w.y, part);
-                part = fmaf(gp.z, w.z, part);
-                part = fmaf(gp.w, w.w, part);
+                gm = fmaf(gp.x, w.x, gm);
+                gm = fmaf(gp.y, w.y, gm);
+                gm = fmaf(gp.z, w.z, gm);
+                gm = fmaf(gp.w, w.w, gm);
             }
+            part = gm + part;
         }
         const float total = part + __shfl_xor(part, 32) + a.bp;
         const int64_t b = base + j;
@@ -799,6 +802,24 @@ __global__ __launch_bounds__(256) void gmf_tile_kernel(GmfTileArgs a)
     }
 }
 
+// largest finite positive element of x[0, n) into *out (a float's bit pattern; the caller zeroes it): layer1_scale()'s input
+__global__ __launch_bounds__(256) void posmax_kernel(const float* __restrict__ x, int64_t n, unsigned int* out)
+{
+    float m = 0.f;
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (v[c] > m && v[c] < __builtin_inff()) m = v[c];
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        if (x[i] > m && x[i] < __builtin_inff()) m = x[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+
 template <int G, bool L3>
 int launch_tile_t(const TileArgs& a, hipStream_t s)
 {
@@ -890,10 +911,12 @@ int tower_launch_tile(int G, int has_l3, const float* img, const float* P, const
                       const float* EUg, const float* EIg, const int64_t* users, const int64_t* cands,
                       int64_t user_base, int64_t n_users, int64_t n_items, int64_t U, int64_t N,
                       float* out, int64_t ld_out, float bp, int act, float lo, float hi, int32_t* oob,
-                      unsigned int* next_tile, hipStream_t s)
+                      unsigned int* next_tile, const float* pmax, const float* qmax, hipStream_t s)
 {
     if (U <= 0 || N <= 0) return RECO_OK;
-    TileArgs a{img, P, Q, EUg, EIg, users, cands, user_base, n_users, n_items, U, N, out, ld_out, bp, act, lo, hi, oob, next_tile};
+    RECO_REQUIRE(pmax && qmax, "tower tile kernel: the layer-1 maxima of this call are missing");
+    TileArgs a{img, P, Q, EUg, EIg, users, cands, user_base, n_users, n_items, U, N, out, ld_out, bp, act, lo, hi, oob, next_tile,
+               pmax, qmax};
     if (G == 32 && has_l3) return launch_tile_t<32, true>(a, s);
     if (G == 0 && has_l3) return launch_tile_t<0, true>(a, s);
     if (G == 64 && !has_l3) return launch_tile_t<64, false>(a, s);
@@ -943,6 +966,16 @@ int gmf_launch_tile(const float* EUg, const float* EIg, const float* wp, const i
     return RECO_OK;
 }
 
+// *out (zeroed by the caller, on this stream) = bit pattern of the largest finite positive element of x[0, n)
+int tower_launch_posmax(const float* x, int64_t n, unsigned int* out, hipStream_t s)
+{
+    if (n <= 0) return RECO_OK;
+    const int64_t blocks = ceil_div64(n, 256 * 16);
+    hipLaunchKernelGGL(posmax_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, s, x, n, out);
+    RECO_CHECK_LAUNCH();
+    return RECO_OK;
+}
+
 // ---- fused score + top-k (tower_tile_topk_kernel) ----
 int tower_tile_users_per_block(int G) { (void)G; return 24; }
 
@@ -956,12 +989,15 @@ int tower_launch_tile_topk(int G, int has_l3, const float* img, const float* P, 
                            const float* EUg, const float* EIg, const int64_t* users, const int64_t* cands,
                            int64_t user_base, int64_t n_users, int64_t n_items, int64_t U, int64_t N,
                            float bp, int act, float lo, float hi, int32_t* oob,
-                           int k, int v_max, unsigned int* counters, unsigned long long* partial, hipStream_t s)
+                           int k, int v_max, unsigned int* counters, unsigned long long* partial,
+                           const float* pmax, const float* qmax, hipStream_t s)
 {
     if (U <= 0 || N <= 0) return RECO_OK;
+    RECO_REQUIRE(pmax && qmax, "fused top-k tile kernel: the layer-1 maxima of this call are missing");
     RECO_REQUIRE(k >= 1 && k <= 128 && v_max >= 1 && v_max <= 1024, "fused top-k: k=%d / v_max=%d out of range", k, v_max);
     RECO_REQUIRE(N < (1ll << 31) && ceil_div64(U, 16) < (1ll << 21), "fused top-k: problem too large for one launch");
-    TileArgs a{img, P, Q, EUg, EIg, users, cands, user_base, n_users, n_items, U, N, nullptr, 0, bp, act, lo, hi, oob, nullptr};
+    TileArgs a{img, P, Q, EUg, EIg, users, cands, user_base, n_users, n_items, U, N, nullptr, 0, bp, act, lo, hi, oob, nullptr,
+               pmax, qmax};
     const int64_t blocks = ceil_div64(U, tower_tile_users_per_block(G));
     TopkFuse f{k, v_max, counters, counters + 64, counters + 64 + blocks, partial};
     if (k <= 64) {

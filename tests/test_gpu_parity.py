@@ -526,3 +526,33 @@ def test_topk_many_short_rows_lane_kernel():
         assert np.array_equal(ids.cpu().numpy(), oid), (rows, N, k, pad)
         got = vals.cpu().numpy()
         assert np.array_equal(np.isnan(got), np.isnan(oval)) and np.array_equal(np.nan_to_num(got), np.nan_to_num(oval)), (rows, N, k, pad)
+
+
+@pytest.mark.parametrize("scale", [1e-6, 0.01, 1.0, 25.0, 3000.0])
+def test_tile_kernels_equal_the_pair_kernel_bit_for_bit_at_any_embedding_scale(scale):
+    """The tile kernels compute layer 1 as ONE clamped add per element on activations scaled by a per-call power of two
+    (tower_shared.h layer1_scale); the pair-list kernel computes relu(P + Q) unscaled.  Scaling by a power of two commutes with
+    every rounding, so score_matrix / score_topk must reproduce score_pairs to the bit whatever the size of the embeddings
+    (MLP-only model; with a GMF half the two kernels round its products in a different order and agree to ~1e-7)."""
+    from recommender_amd.helpers import NCF
+    torch.manual_seed(21)
+    for name in ("NeuMF-end", "MLP"):
+        m = NCF(211, 333, 32, 3, 0.0, name).eval()
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if "embed" in n:
+                    p.mul_(100.0 * scale)
+        m = m.cuda()
+        t = m._tower(torch.device("cuda", 0))
+        uu, ii = torch.meshgrid(torch.arange(211), torch.arange(333), indexing="ij")
+        pairs = t.score_pairs(uu.reshape(-1).cuda(), ii.reshape(-1).cuda()).view(211, 333)
+        full = t.score_matrix()
+        if name == "MLP":      # no GMF half (the tile kernels fold the predict weights into the user's GMF row, the pair kernel
+            assert torch.equal(pairs.view(torch.int32), full.view(torch.int32)), (name, scale)     # multiplies them last)
+        else:
+            torch.testing.assert_close(full, pairs, rtol=2e-6, atol=1e-6 * float(pairs.abs().max()))
+        ids, vals = t.score_topk(None, 7)
+        fids, fvals = t.score_topk(None, 7, fused=True)
+        oid, oval = O.topk_rows(full.cpu().numpy(), 7)
+        for a, b in ((ids, vals), (fids, fvals)):
+            assert np.array_equal(a.cpu().numpy(), oid) and np.array_equal(b.cpu().numpy().view(np.uint32), oval.view(np.uint32))
