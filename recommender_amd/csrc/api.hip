@@ -15,12 +15,13 @@ int tower_launch_tile(int G, int has_l3, const float* img, const float* P, const
                       const float* EUg, const float* EIg, const int64_t* users, const int64_t* cands,
                       int64_t user_base, int64_t n_users, int64_t n_items, int64_t U, int64_t N,
                       float* out, int64_t ld_out, float bp, int act, float lo, float hi, int32_t* oob,
-                      unsigned int* next_tile, const float* pmax, const float* qmax, hipStream_t s);
-int tower_launch_posmax(const float* x, int64_t n, unsigned int* out, hipStream_t s);
+                      unsigned int* next_tile, const float* l1, hipStream_t s);
+int tower_launch_l1scale(const float* W1, const float* b1, int dm, const float* u_rows, int64_t u_elems,
+                         const float* i_rows, int64_t i_elems, unsigned int* scratch, float* out, hipStream_t s);
 int tower_launch_pairs(int G, int has_l3, const float* img, const float* P, const float* Q,
                        const float* EUg, const float* EIg, const int64_t* user, const int64_t* item,
                        int64_t n_users, int64_t n_items, int64_t B, float* out, float bp, int act,
-                       float lo, float hi, int32_t* oob, hipStream_t s);
+                       float lo, float hi, int32_t* oob, const float* l1, hipStream_t s);
 // launchers defined in tower_split.hip (RECO_PREC_SPLIT_BF16X3)
 size_t tower_split_image_bytes(int has_l3);
 int tower_pack_split_image(const float* W2, const float* W3, int has_l3, const float* img, void* out, hipStream_t s);
@@ -40,7 +41,7 @@ int tower_launch_tile_topk(int G, int has_l3, const float* img, const float* P, 
                            int64_t user_base, int64_t n_users, int64_t n_items, int64_t U, int64_t N,
                            float bp, int act, float lo, float hi, int32_t* oob,
                            int k, int v_max, unsigned int* counters, unsigned long long* partial,
-                           const float* pmax, const float* qmax, hipStream_t s);
+                           const float* l1, hipStream_t s);
 int gmf_launch_pairs(const float* EUg, const float* EIg, const float* wp, const int64_t* user,
                      const int64_t* item, int64_t n_users, int64_t n_items, int64_t B, int G, float* out,
                      float bp, int act, float lo, float hi, int32_t* oob, hipStream_t s);
@@ -216,23 +217,29 @@ struct reco_tower {
     void* img_split;  // bf16x3 image (RECO_PREC_SPLIT_BF16X3 only)
     float* P;         // [n_users,128] layer-1 user projection (+ b1)
     float* Q;         // [n_items,128] layer-1 item projection
-    unsigned int* qmax;  // device word: largest finite positive element of Q (a float's bits), for layer1_scale() in the tile kernels
+    float* l1;        // device words {s, 1/s}: the power of two layer 1 is scaled by (tower_shared.h), fixed by the handle's tables;
+                      // null in split mode and for handles without tables (then per call, resolve_l1)
     int device;
 };
 
+// Layer-1 scale words {s, 1/s} (tower_shared.h).  Inside a 256-byte block: floats at words kL1Word, kL1Word + 1, two scratch
+// words for the maxima behind them.  The handle owns such a block when it has tables; calls over row blocks handed in per call
+// compute theirs into the head of the call workspace (word 0 of that head is the tile work-queue counter).
+static const int kL1Word = 16, kL1ScratchWord = 20;
+
 static int tower_project(const reco_tower* t, const float* u_rows, const int64_t* u_idx, int64_t u_limit, int64_t U,
                          const float* i_rows, const int64_t* i_idx, int64_t i_limit, int64_t N,
-                         float* P, float* Q, int32_t* oob, hipStream_t s)
+                         float* P, float* Q, int32_t* oob, const float* l1, hipStream_t s)
 {
     const int dm = t->d.dm;
     if (U > 0) {
         int rc = launch_linear_f32(u_rows, dm, u_idx, u_limit, U, t->d.W[0], 2 * dm, t->d.b[0], H1, dm, RECO_ACT_NONE,
-                                   0.f, 0.f, P, H1, oob, nullptr, 0, s);
+                                   0.f, 0.f, P, H1, oob, nullptr, 0, s, 0, l1);
         if (rc) return rc;
     }
     if (N > 0) {
         int rc = launch_linear_f32(i_rows, dm, i_idx, i_limit, N, t->d.W[0] + dm, 2 * dm, nullptr, H1, dm,
-                                   RECO_ACT_NONE, 0.f, 0.f, Q, H1, oob, nullptr, 0, s);
+                                   RECO_ACT_NONE, 0.f, 0.f, Q, H1, oob, nullptr, 0, s, 0, l1);
         if (rc) return rc;
     }
     return RECO_OK;
@@ -249,14 +256,14 @@ static int check_device(const reco_tower* t, const char* who)
 
 static int run_pairs(const reco_tower* t, const float* P, const float* Q, const float* EUg, const float* EIg,
                      const int64_t* user, const int64_t* item, int64_t n_users, int64_t n_items, int64_t B, float* out,
-                     int32_t* oob, hipStream_t s)
+                     int32_t* oob, const float* l1, hipStream_t s)
 {
     const reco_tower_desc_t& d = t->d;
     if (t->img_split)
         return tower_launch_pairs_split(t->G, t->has_l3, t->img_split, P, Q, EUg, EIg, user, item, n_users, n_items, B,
                                         out, t->bp, d.act, d.lo, d.hi, oob, s);
     return tower_launch_pairs(t->G, t->has_l3, t->img, P, Q, EUg, EIg, user, item, n_users, n_items, B, out, t->bp,
-                              d.act, d.lo, d.hi, oob, s);
+                              d.act, d.lo, d.hi, oob, l1, s);
 }
 
 extern "C" void reco_tower_destroy(reco_tower_t* t)
@@ -266,7 +273,7 @@ extern "C" void reco_tower_destroy(reco_tower_t* t)
     (void)hipFree(t->img_split);
     (void)hipFree(t->P);
     (void)hipFree(t->Q);
-    (void)hipFree(t->qmax);
+    (void)hipFree(t->l1);
     delete t;
 }
 
@@ -324,7 +331,7 @@ extern "C" int reco_tower_create(const reco_tower_desc_t* d, void* stream, reco_
     if (e == hipSuccess && split) e = hipMalloc(&t->img_split, tower_split_image_bytes(t->has_l3));
     if (e == hipSuccess && t->mfma && tables) e = hipMalloc(&t->P, (size_t)d->n_users * H1 * sizeof(float));
     if (e == hipSuccess && t->mfma && tables) e = hipMalloc(&t->Q, (size_t)d->n_items * H1 * sizeof(float));
-    if (e == hipSuccess && t->mfma && tables) e = hipMalloc(&t->qmax, 256);
+    if (e == hipSuccess && t->mfma && tables && !split) e = hipMalloc(&t->l1, 256);
     if (e == hipSuccess) e = hipMemcpyAsync(&t->bp, d->b_predict, sizeof(float), hipMemcpyDeviceToHost, s);
     if (e != hipSuccess) {
         reco_set_error("tower_create: %s", hipGetErrorString(e));
@@ -336,13 +343,11 @@ extern "C" int reco_tower_create(const reco_tower_desc_t* d, void* stream, reco_
                               d->w_predict, t->G, t->has_l3, t->img, s);
         if (!rc && split)
             rc = tower_pack_split_image(d->W[1], t->has_l3 ? d->W[2] : nullptr, t->has_l3, t->img, t->img_split, s);
+        if (!rc && tables && t->l1)       // the layer-1 scale of every pair these tables can form, before anything is projected
+            rc = tower_launch_l1scale(d->W[0], d->b[0], d->dm, d->user_mlp, d->n_users * d->dm, d->item_mlp, d->n_items * d->dm,
+                                      reinterpret_cast<unsigned int*>(t->l1) + kL1ScratchWord, t->l1, s);
         if (!rc && tables)
-            rc = tower_project(t, d->user_mlp, nullptr, 0, d->n_users, d->item_mlp, nullptr, 0, d->n_items, t->P, t->Q, nullptr, s);
-        if (!rc && tables) {
-            e = hipMemsetAsync(t->qmax, 0, 256, s);
-            if (e != hipSuccess) { reco_set_error("tower_create: %s", hipGetErrorString(e)); rc = RECO_EHIP; }
-            else rc = tower_launch_posmax(t->Q, d->n_items * H1, t->qmax, s);
-        }
+            rc = tower_project(t, d->user_mlp, nullptr, 0, d->n_users, d->item_mlp, nullptr, 0, d->n_items, t->P, t->Q, nullptr, t->l1, s);
     }
     if (!rc) {
         e = hipStreamSynchronize(s);
@@ -367,7 +372,20 @@ extern "C" int reco_tower_score_pairs(reco_tower_t* t, const int64_t* user, cons
         return gmf_launch_pairs(d.user_gmf, d.item_gmf, d.w_predict, user, item, d.n_users, d.n_items, B, d.dg, out,
                                 t->bp, d.act, d.lo, d.hi, oob, s);
     ProfScope prof(s);
-    return run_pairs(t, t->P, t->Q, d.user_gmf, d.item_gmf, user, item, d.n_users, d.n_items, B, out, oob, s);
+    return run_pairs(t, t->P, t->Q, d.user_gmf, d.item_gmf, user, item, d.n_users, d.n_items, B, out, oob, t->l1, s);
+}
+
+// the scale for a call: the handle's own, or -- a handle without tables -- computed over the row blocks of this call into `head`
+static int resolve_l1(const reco_tower* t, const float* u_rows, int64_t U, const float* i_rows, int64_t N, unsigned int* head,
+                      const float** l1, hipStream_t s)
+{
+    *l1 = nullptr;
+    if (!t->mfma || t->img_split) return RECO_OK;        // GMF-only models have no layer 1; the split mode runs unscaled
+    if (t->l1) { *l1 = t->l1; return RECO_OK; }
+    RECO_REQUIRE(head, "internal: no workspace head for the layer-1 scale");
+    float* out = reinterpret_cast<float*>(head + kL1Word);
+    *l1 = out;
+    return tower_launch_l1scale(t->d.W[0], t->d.b[0], t->d.dm, u_rows, U * t->d.dm, i_rows, N * t->d.dm, head + kL1ScratchWord, out, s);
 }
 
 extern "C" size_t reco_tower_rows_workspace_bytes(int64_t B)
@@ -396,24 +414,24 @@ extern "C" int reco_tower_score_rows(reco_tower_t* t, const float* u_gmf, const 
     if (!ws || ws_bytes < 2 * half) { reco_set_error("score_rows: workspace too small (%zu < %zu)", ws_bytes, 2 * half); return RECO_ENOMEM; }
     float* P = static_cast<float*>(ws);
     float* Q = reinterpret_cast<float*>(static_cast<char*>(ws) + half);
-    int rc = tower_project(t, u_mlp, nullptr, 0, B, i_mlp, nullptr, 0, B, P, Q, nullptr, s);
+    // These rows are not the handle's tables and each is used once: a bound over them would be a pass of its own (measured:
+    // 1M Hybrid rows 1.00 -> 1.18 ms), so the projections stay unscaled and the pair kernel takes its add + max form.
+    int rc = tower_project(t, u_mlp, nullptr, 0, B, i_mlp, nullptr, 0, B, P, Q, nullptr, nullptr, s);
     if (rc) return rc;
     ProfScope prof(s);
-    return run_pairs(t, P, Q, u_gmf, i_gmf, nullptr, nullptr, B, B, B, out, nullptr, s);
+    return run_pairs(t, P, Q, u_gmf, i_gmf, nullptr, nullptr, B, B, B, out, nullptr, nullptr, s);
 }
 
 // ---- matrix / top-k forms ----------------------------------------------------------------------
-// Head of every call workspace (256 bytes): word 0 = tile work-queue counter, word 16 = largest finite positive element of the
-// P rows of the launch, word 32 = the same of the Q rows of the call (float bit patterns, posmax_kernel; tower_shared.h
-// layer1_scale()).  Words 0 and 16 are cleared per launch, word 32 once per call.
+// Head of every call workspace (256 bytes): word 0 = tile work-queue counter (cleared per launch); words kL1Word.. = the
+// call's layer-1 scale when the handle has none of its own (resolve_l1).
 static const size_t kQueueBytes = 256;
-static const int kPmaxWord = 16, kQmaxWord = 32;
 static size_t proj_bytes(int64_t rows) { return align_up((size_t)(rows > 0 ? rows : 0) * H1 * sizeof(float), 256); }
 
 extern "C" size_t reco_tower_matrix_workspace_bytes(int64_t U, int64_t N) { return kQueueBytes + proj_bytes(U) + proj_bytes(N); }
 
 static int score_matrix_impl(reco_tower* t, const int64_t* users, int64_t user_base, int64_t U,
-                             const int64_t* cands, int64_t N, const float* Qready, const unsigned int* qmax_ready,
+                             const int64_t* cands, int64_t N, const float* Qready, const float* l1,
                              float* out, int64_t ld_out, float* P, float* Q, unsigned int* queue, int32_t* oob, hipStream_t s)
 {
     const reco_tower_desc_t& d = t->d;
@@ -422,23 +440,16 @@ static int score_matrix_impl(reco_tower* t, const int64_t* users, int64_t user_b
                                d.dg, out, ld_out, t->bp, d.act, d.lo, d.hi, oob, s);
     // layer-1 projections for exactly these users / candidates, inside the call
     const float* urows = users ? d.user_mlp : d.user_mlp + user_base * d.dm;
-    int rc = tower_project(t, urows, users, d.n_users, U, d.item_mlp, cands, d.n_items, Qready ? 0 : N, P, Q, oob, s);
+    int rc = tower_project(t, urows, users, d.n_users, U, d.item_mlp, cands, d.n_items, Qready ? 0 : N, P, Q, oob, l1, s);
     if (rc) return rc;
-    RECO_REQUIRE(queue && (!Qready || qmax_ready), "score_matrix: internal: workspace head / item-side maximum missing");
-    RECO_CHECK_HIP(hipMemsetAsync(queue, 0, (Qready ? kQmaxWord : kQmaxWord + 1) * sizeof(unsigned int), s));
-    const unsigned int* qmax = Qready ? qmax_ready : queue + kQmaxWord;
-    if (!t->img_split) {             // the exact tile kernels scale layer 1 by these (the split mode does not)
-        if ((rc = tower_launch_posmax(P, U * H1, queue + kPmaxWord, s))) return rc;
-        if (!Qready && (rc = tower_launch_posmax(Q, N * H1, queue + kQmaxWord, s))) return rc;
-    }
+    if (queue) RECO_CHECK_HIP(hipMemsetAsync(queue, 0, sizeof(unsigned int), s));
     ProfScope prof(s);
     if (t->img_split)
         return tower_launch_tile_split(t->G, t->has_l3, t->img_split, P, Qready ? Qready : Q, d.user_gmf, d.item_gmf, users,
                                        cands, user_base, d.n_users, d.n_items, U, N, out, ld_out, t->bp, d.act, d.lo, d.hi,
                                        oob, queue, s);
     return tower_launch_tile(t->G, t->has_l3, t->img, P, Qready ? Qready : Q, d.user_gmf, d.item_gmf, users, cands,
-                             user_base, d.n_users, d.n_items, U, N, out, ld_out, t->bp, d.act, d.lo, d.hi, oob, queue,
-                             reinterpret_cast<const float*>(queue + kPmaxWord), reinterpret_cast<const float*>(qmax), s);
+                             user_base, d.n_users, d.n_items, U, N, out, ld_out, t->bp, d.act, d.lo, d.hi, oob, queue, l1, s);
 }
 
 static int check_ranges(const reco_tower* t, const int64_t* users, int64_t user_base, int64_t U, const int64_t* cands,
@@ -471,7 +482,9 @@ extern "C" int reco_tower_score_matrix(reco_tower_t* t, const int64_t* users, in
         P = reinterpret_cast<float*>(static_cast<char*>(ws) + kQueueBytes);
         Q = reinterpret_cast<float*>(static_cast<char*>(ws) + kQueueBytes + proj_bytes(U));
     }
-    return score_matrix_impl(t, users, user_base, U, cands, N, nullptr, nullptr, out, ld_out, P, Q, queue, oob, (hipStream_t)stream);
+    const float* l1 = nullptr;
+    if ((rc = resolve_l1(t, t->d.user_mlp, t->d.n_users, t->d.item_mlp, t->d.n_items, queue, &l1, (hipStream_t)stream))) return rc;
+    return score_matrix_impl(t, users, user_base, U, cands, N, nullptr, l1, out, ld_out, P, Q, queue, oob, (hipStream_t)stream);
 }
 
 // user-chunk size for the fused score + top-k path
@@ -583,21 +596,15 @@ static int score_topk_fused(reco_tower_t* t, const int64_t* users, int64_t user_
     unsigned long long* partial = reinterpret_cast<unsigned long long*>(w + counter_bytes);
     const bool cached_q = !cands && N == d.n_items && U <= kServingUsers && t->Q;     // as the unfused form below
     int rc = RECO_OK;
-    unsigned int* head = static_cast<unsigned int*>(ws);       // layer-1 maxima live in the workspace head (no tile queue here)
-    const unsigned int* qmax = head + kQmaxWord;
-    if (cached_q) { Q = t->Q; qmax = t->qmax; }
-    else {
-        if ((rc = tower_project(t, nullptr, nullptr, 0, 0, d.item_mlp, cands, d.n_items, N, nullptr, Q, oob, s))) return rc;
-        RECO_CHECK_HIP(hipMemsetAsync(head + kQmaxWord, 0, sizeof(unsigned int), s));
-        if ((rc = tower_launch_posmax(Q, N * H1, head + kQmaxWord, s))) return rc;
-    }
+    const float* l1 = nullptr;
+    if ((rc = resolve_l1(t, d.user_mlp, d.n_users, d.item_mlp, d.n_items, static_cast<unsigned int*>(ws), &l1, s))) return rc;
+    if (cached_q) Q = t->Q;
+    else if ((rc = tower_project(t, nullptr, nullptr, 0, 0, d.item_mlp, cands, d.n_items, N, nullptr, Q, oob, l1, s))) return rc;
     for (int64_t c0 = 0; c0 < U; c0 += Uc) {
         const int64_t n = U - c0 < Uc ? U - c0 : Uc;
         const int64_t* ul = users ? users + c0 : nullptr;
         const float* urows = ul ? d.user_mlp : d.user_mlp + (user_base + c0) * d.dm;
-        if ((rc = tower_project(t, urows, ul, d.n_users, n, nullptr, nullptr, 0, 0, P, nullptr, oob, s))) return rc;
-        RECO_CHECK_HIP(hipMemsetAsync(head, 0, kQmaxWord * sizeof(unsigned int), s));
-        if ((rc = tower_launch_posmax(P, n * H1, head + kPmaxWord, s))) return rc;
+        if ((rc = tower_project(t, urows, ul, d.n_users, n, nullptr, nullptr, 0, 0, P, nullptr, oob, l1, s))) return rc;
         // hand-out counters and partial lists start at zero (a list nobody wrote reads as empty)
         int v = fuse_visitors(t->G, n, N, k);                                    // a short last chunk may take more lists per block
         if ((int64_t)v * n > list_room) v = (int)(list_room / n);
@@ -605,8 +612,7 @@ static int score_topk_fused(reco_tower_t* t, const int64_t* users, int64_t user_
         {
             ProfScope prof(s);
             rc = tower_launch_tile_topk(t->G, t->has_l3, t->img, P, Q, d.user_gmf, d.item_gmf, ul, cands, user_base + c0, d.n_users,
-                                        d.n_items, n, N, t->bp, d.act, d.lo, d.hi, oob, k, v, counters, partial,
-                                        reinterpret_cast<const float*>(head + kPmaxWord), reinterpret_cast<const float*>(qmax), s);
+                                        d.n_items, n, N, t->bp, d.act, d.lo, d.hi, oob, k, v, counters, partial, l1, s);
         }
         if (rc) return rc;
         if ((rc = launch_topk_merge(partial, n, v, k, out_ids + c0 * k, out_scores + c0 * k, s))) return rc;
@@ -649,19 +655,16 @@ static int score_topk_impl(reco_tower_t* t, const int64_t* users, int64_t user_b
     // item-side projection once per call.  Request-sized calls over the whole catalog (a handful of users: the serving
     // path, inference_engine.py:149-166) reuse the projection of all items that the handle packed at creation instead.
     const bool cached_q = t->mfma && !cands && N == d.n_items && U <= kServingUsers && t->Q;
-    const unsigned int* qmax = queue ? queue + kQmaxWord : nullptr;      // the item side's layer-1 maximum, once per call
-    if (cached_q) { Q = t->Q; qmax = t->qmax; }
+    const float* l1 = nullptr;
+    if ((rc = resolve_l1(t, d.user_mlp, d.n_users, d.item_mlp, d.n_items, queue, &l1, s))) return rc;
+    if (cached_q) Q = t->Q;
     else if (t->mfma) {
-        rc = tower_project(t, nullptr, nullptr, 0, 0, d.item_mlp, cands, d.n_items, N, nullptr, Q, oob, s);
+        rc = tower_project(t, nullptr, nullptr, 0, 0, d.item_mlp, cands, d.n_items, N, nullptr, Q, oob, l1, s);
         if (rc) return rc;
-        if (!t->img_split) {
-            RECO_CHECK_HIP(hipMemsetAsync(queue + kQmaxWord, 0, sizeof(unsigned int), s));
-            if ((rc = tower_launch_posmax(Q, N * H1, queue + kQmaxWord, s))) return rc;
-        }
     }
     for (int64_t c0 = 0; c0 < U; c0 += Uc) {
         const int64_t n = U - c0 < Uc ? U - c0 : Uc;
-        rc = score_matrix_impl(t, users ? users + c0 : nullptr, user_base + c0, n, cands, N, Q, qmax, scores, ldN, P, Q, queue, oob, s);
+        rc = score_matrix_impl(t, users ? users + c0 : nullptr, user_base + c0, n, cands, N, Q, l1, scores, ldN, P, Q, queue, oob, s);
         if (rc) return rc;
         rc = launch_topk_rows(scores, n, N, ldN, k, exclude ? exclude + c0 * ld_ex : nullptr, ld_ex, out_ids + c0 * k,
                               out_scores + c0 * k, tws, tws_bytes, s);
@@ -716,7 +719,8 @@ static int rows_view(const reco_tower_t* t, const float* u_gmf, const float* i_g
     *v = *t;
     v->d.user_gmf = u_gmf; v->d.item_gmf = i_gmf; v->d.user_mlp = u_mlp; v->d.item_mlp = i_mlp;
     v->d.n_users = U; v->d.n_items = N;
-    v->P = nullptr; v->Q = nullptr;        // the handle's cached projections belong to its own tables
+    v->P = nullptr; v->Q = nullptr;        // the handle's cached projections and layer-1 scale belong to its own tables
+    v->l1 = nullptr;
     return RECO_OK;
 }
 

@@ -64,6 +64,8 @@ struct LinArgs {
     float* partial;        // [splits][M][N] raw accumulators when splits > 1
     int a_trans;           // A is stored [K, M] (row stride lda): C = act(A^T W^T + bias)
     int bias_rows;         // bias indexed by output row m instead of column n
+    const float* out_scale;  // nullable device word: every output is multiplied by it after bias + activation (the tower's layer-1
+                             // projections are written pre-scaled by a power of two, tower_shared.h layer1_scale)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float lo, float hi)
@@ -345,6 +347,7 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
     }
 
     // epilogue: D[row = (r&3) + 8 (r>>2) + 4 h][col = lane & 31]
+    const float osc = a.out_scale ? a.out_scale[0] : 1.f;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int64_t n = n0 + wn * (BN / 2) + tn * 32 + i;
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
                 if (acc[tm][tn][r] != 12345.678f) continue;
 #endif
                 if (a.splits > 1) a.partial[((int64_t)split * a.M + m) * a.N + n] = acc[tm][tn][r];
-                else a.C[m * a.ldc + n] = apply_act(acc[tm][tn][r] + ((a.bias && a.bias_rows) ? a.bias[m] : bv), a.act, a.lo, a.hi);
+                else a.C[m * a.ldc + n] = apply_act(acc[tm][tn][r] + ((a.bias && a.bias_rows) ? a.bias[m] : bv), a.act, a.lo, a.hi) * osc;
             }
         }
     }
@@ -370,11 +373,12 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(LinArgs a)
 {
     const int64_t total = a.M * a.N;
+    const float osc = a.out_scale ? a.out_scale[0] : 1.f;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         float v = a.partial[e];
         for (int sp = 1; sp < a.splits; ++sp) v += a.partial[(int64_t)sp * total + e];
         const int64_t m = e / a.N, n = e - m * a.N;
-        a.C[m * a.ldc + n] = apply_act(v + (a.bias ? a.bias[a.bias_rows ? m : n] : 0.f), a.act, a.lo, a.hi);
+        a.C[m * a.ldc + n] = apply_act(v + (a.bias ? a.bias[a.bias_rows ? m : n] : 0.f), a.act, a.lo, a.hi) * osc;
     }
 }
 
@@ -461,7 +465,7 @@ size_t linear_workspace_bytes(int64_t M, int64_t N, int64_t K)
 int launch_linear_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_t a_row_limit, int64_t M,
                       const float* W, int64_t ldw, const float* bias, int64_t N, int64_t K,
                       int act, float lo, float hi, float* C, int64_t ldc, int32_t* oob,
-                      void* ws, size_t ws_bytes, hipStream_t s, int flags)
+                      void* ws, size_t ws_bytes, hipStream_t s, int flags, const float* out_scale)
 {
     if (M <= 0 || N <= 0) return RECO_OK;
     const bool at = (flags & RECO_LINEAR_A_TRANSPOSED) != 0;
@@ -470,7 +474,7 @@ int launch_linear_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_
     RECO_REQUIRE(lda >= (at ? M : K) && ldw >= K && ldc >= N, "linear: leading dimension smaller than the row");
     RECO_REQUIRE(!(at && a_rows), "linear: row gather and transposed A cannot be combined");
     LinArgs a{A, lda, a_rows, a_rows ? a_row_limit : M, M, W, ldw, bias, N, K, act, lo, hi, C, ldc, oob, 1, K, nullptr,
-              at ? 1 : 0, (flags & RECO_LINEAR_BIAS_PER_ROW) ? 1 : 0};
+              at ? 1 : 0, (flags & RECO_LINEAR_BIAS_PER_ROW) ? 1 : 0, out_scale};
     int vec = 1;
     const bool a4 = at || (lda % 4 == 0 && (uintptr_t)A % 16 == 0), a2 = at || (lda % 2 == 0 && (uintptr_t)A % 8 == 0);
     if (a4 && ldw % 4 == 0 && (uintptr_t)W % 16 == 0) vec = 4;

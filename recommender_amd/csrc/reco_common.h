@@ -72,7 +72,7 @@ struct TowerImage;  // opaque here
 int launch_linear_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_t a_row_limit, int64_t M,
                       const float* W, int64_t ldw, const float* bias, int64_t N, int64_t K,
                       int act, float lo, float hi, float* C, int64_t ldc, int32_t* oob,
-                      void* ws, size_t ws_bytes, hipStream_t s, int flags = 0);
+                      void* ws, size_t ws_bytes, hipStream_t s, int flags = 0, const float* out_scale = nullptr);
 size_t linear_workspace_bytes(int64_t M, int64_t N, int64_t K);
 
 int launch_topk_rows(const float* scores, int64_t rows, int64_t N, int64_t ld, int k,

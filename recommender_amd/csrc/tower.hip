@@ -202,8 +202,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
     const int64_t tiles_n = (a.N + TI - 1) / TI;
     const int64_t tiles = tiles_n * ((a.U + TUB - 1) / TUB);
 
-    const Layer1Scale l1 = layer1_scale(a.pmax, a.qmax);
-    load_image_scaled<L3, TILE_THREADS>(s_img, a.img, tid, l1);
+    load_image_scaled<L3, TILE_THREADS>(s_img, a.img, tid, layer1_scale(a.l1));
 
     f32x4 pst[NP];
     auto p_stage_load = [&](int64_t t) {
@@ -220,7 +219,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
 #pragma unroll
         for (int s = 0; s < NP; ++s)
             if (tid + s * TILE_THREADS < TUB * (H1 / 4))
-                reinterpret_cast<f32x4*>(s_pbuf + buf * TUB * H1)[tid + s * TILE_THREADS] = pst[s] * l1.s;
+                reinterpret_cast<f32x4*>(s_pbuf + buf * TUB * H1)[tid + s * TILE_THREADS] = pst[s];
     };
 
 #ifdef RECO_DIAG_CLOCK
@@ -232,7 +231,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
     tile_queue_fetch(a, tid, tile + gridDim.x, &s_next[0]);
     if (tile < tiles) {
         tile_stage_load<G, THREADS>(a, (tile % tiles_n) * TI, tile / tiles_n == 0, tid, st);
-        tile_stage_store<G, THREADS>(s_buf, s_buf + TI * QS, tid, st, l1.s);
+        tile_stage_store<G, THREADS>(s_buf, s_buf + TI * QS, tid, st);
         p_stage_load(tile);
         p_stage_store(0);
     }
@@ -276,7 +275,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
                         return PQ{*reinterpret_cast<const f32x4*>(qrow + 8 * q), *reinterpret_cast<const f32x4*>(prow + 8 * q)};
                     }
                     __device__ __forceinline__ void pre(int) const {}
-                    __device__ __forceinline__ f32x4 finish(int, const PQ& v) const { return add_clamp4(v.p, v.q); }   // = s * relu(p + q)
+                    __device__ __forceinline__ f32x4 finish(int, const PQ& v) const { return add_clamp4(v.p, v.q); }   // = s * relu(p + q), P / Q pre-scaled
                     __device__ __forceinline__ f32x4 passthrough(const PQ& v) const { return v.q; }
                     const float* grow;     // this pair's GMF item row half in LDS
                     const f32x4* gu;       // the user's GMF row half, predict weights folded in
@@ -304,7 +303,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
         }
         if (next < tiles) {
             float* d_q = s_buf + ((it + 1) & 1) * BUF;
-            tile_stage_store<G, THREADS>(d_q, d_q + TI * QS, tid, st, l1.s);
+            tile_stage_store<G, THREADS>(d_q, d_q + TI * QS, tid, st);
             p_stage_store((it + 1) & 1);
         }
         __syncthreads();   // tile i fully consumed, tile i + 1 fully staged
@@ -369,8 +368,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_topk_kernel
     const unsigned tiles_n = (unsigned)((a.N + TI - 1) / TI);
     const unsigned blocks_u = (unsigned)((a.U + TUB - 1) / TUB);
 
-    const Layer1Scale l1 = layer1_scale(a.pmax, a.qmax);
-    load_image_scaled<L3, TILE_THREADS>(s_img, a.img, tid, l1);
+    load_image_scaled<L3, TILE_THREADS>(s_img, a.img, tid, layer1_scale(a.l1));
 
     // ---- hand-out (wave 0; every value below is wave-uniform): the tile fetched last belongs to (q_blk, q_v) ----
     constexpr int LIST_SHIFT = 10;                             // published as block << 10 | visitor slot
@@ -456,7 +454,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_topk_kernel
 #pragma unroll
         for (int s = 0; s < NP; ++s)
             if (tid + s * TILE_THREADS < TUB * (H1 / 4))
-                reinterpret_cast<f32x4*>(s_pbuf)[tid + s * TILE_THREADS] = pst[s] * l1.s;
+                reinterpret_cast<f32x4*>(s_pbuf)[tid + s * TILE_THREADS] = pst[s];
     };
 
     // ---- per-wave top-k state: one sorted list per owned user ----
@@ -492,7 +490,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_topk_kernel
     unsigned cur_blkv = s_blkv[0], cur_t = s_t[0];
     if (cur_t != ~0u) {
         tile_stage_load<G, THREADS>(a, (int64_t)cur_t * TI, (cur_blkv >> LIST_SHIFT) == 0, tid, st);
-        tile_stage_store<G, THREADS>(s_buf, s_buf + TI * QS, tid, st, l1.s);
+        tile_stage_store<G, THREADS>(s_buf, s_buf + TI * QS, tid, st);
         p_stage_load(cur_blkv >> LIST_SHIFT);
         p_stage_store();
     }
@@ -543,7 +541,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_topk_kernel
                         return PQ{*reinterpret_cast<const f32x4*>(qrow + 8 * q), *reinterpret_cast<const f32x4*>(prow + 8 * q)};
                     }
                     __device__ __forceinline__ void pre(int) const {}
-                    __device__ __forceinline__ f32x4 finish(int, const PQ& v) const { return add_clamp4(v.p, v.q); }   // = s * relu(p + q)
+                    __device__ __forceinline__ f32x4 finish(int, const PQ& v) const { return add_clamp4(v.p, v.q); }   // = s * relu(p + q), P / Q pre-scaled
                     __device__ __forceinline__ f32x4 passthrough(const PQ& v) const { return v.q; }
                     const float* grow;     // this pair's GMF item row half in LDS
                     const f32x4* gu;       // the user's GMF row half, predict weights folded in
@@ -587,7 +585,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_topk_kernel
         }
         if (nxt_t != ~0u) {
             float* d_q = s_buf + ((it + 1) & 1) * BUF;
-            tile_stage_store<G, THREADS>(d_q, d_q + TI * QS, tid, st, l1.s);
+            tile_stage_store<G, THREADS>(d_q, d_q + TI * QS, tid, st);
         }
         if (wave == 0) fetch(it & 1);                          // slot it & 1 was read as `nxt` two barriers ago
         __syncthreads();   // tile fully consumed, next tile fully staged, the tile after next published
@@ -607,7 +605,9 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_topk_kernel
 // LDS staging area.  The layer-1 activations are staged one K half at a time (tower_shared.h): the first half before quad 0,
 // the second -- into the same 8.7 KB -- right before quad 8 is read (LDS operations of one wave execute in issue order, so the
 // overwrite needs no barrier).  With half rows 8 waves fit next to the image (148 KB): 2 waves per SIMD.
-template <int G, bool L3, int WAVES, bool BIG>
+// CLAMP: P and Q were written pre-scaled and layer 1 is the clamped add (tower_shared.h); without it (a.l1 null: row blocks
+// handed in per call, where a bound over the rows would cost a pass of its own) layer 1 is the plain add + max.
+template <int G, bool L3, int WAVES, bool BIG, bool CLAMP>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_kernel(PairArgs a)
 {
     constexpr int GS = G + 4;
@@ -623,9 +623,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_kernel(Pair
     float* s_x = smem + LDS_IMG_SIZE<L3> + wave * WAVE_FLOATS;   // [32][HS]  relu(P+Q), one K half of this wave's pairs
     float* s_gp = s_x + 32 * HS;                          // [32][GS]  gmf products
 
-    for (int i = tid; i < IMG_SIZE / 4; i += 64 * WAVES)
-        if (L3 || i < IMG_W3 / 4 || i >= IMG_B2 / 4)
-            reinterpret_cast<f32x4*>(s_img)[lds_img<L3>(4 * i) / 4] = reinterpret_cast<const f32x4*>(a.img)[i];
+    load_image_scaled<L3, 64 * WAVES>(s_img, a.img, tid, CLAMP ? layer1_scale(a.l1) : Layer1Scale{1.f, 1.f});
     __syncthreads();
 
     const int64_t ngroups = (a.B + 31) / 32;
@@ -648,7 +646,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_kernel(Pair
     for (; grp < ngroups; grp += stride) {
         const int64_t base = grp * 32;
         const bool more = grp + stride < ngroups;
-        pair_store_half(s_x, lane, pf, qf);
+        pair_store_half<CLAMP>(s_x, lane, pf, qf);
         if constexpr (G > 0) pair_store_gmf<G>(s_gp, lane, gu, gi);
         __builtin_amdgcn_wave_barrier();
         // the second half (ps / qs) still belongs to THIS group: the next group's ids wait in other registers until it is stored
@@ -672,7 +670,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_kernel(Pair
             __device__ __forceinline__ void pre(int q) const
             {
                 if (q == 8) {                 // quads 0..7 have all been read: stage the second half, refill its registers
-                    pair_store_half(s_x, lane, ps, qs);
+                    pair_store_half<CLAMP>(s_x, lane, ps, qs);
                     __builtin_amdgcn_wave_barrier();
                     if (more) pair_load_half<BIG>(a, nu, ni, lane, 1, ps, qs);
                 }
@@ -802,22 +800,49 @@ __global__ __launch_bounds__(256) void gmf_tile_kernel(GmfTileArgs a)
     }
 }
 
-// largest finite positive element of x[0, n) into *out (a float's bit pattern; the caller zeroes it): layer1_scale()'s input
-__global__ __launch_bounds__(256) void posmax_kernel(const float* __restrict__ x, int64_t n, unsigned int* out)
+// largest finite |element| of x[0, n) into *out (a float's bit pattern; the caller zeroes it)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t n, unsigned int* out)
 {
     float m = 0.f;
     const int64_t n4 = n / 4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (v[c] > m && v[c] < __builtin_inff()) m = v[c];
+        for (int c = 0; c < 4; ++c) {
+            const float av = fabsf(v[c]);
+            if (av > m && av < __builtin_inff()) m = av;
+        }
     }
-    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        if (x[i] > m && x[i] < __builtin_inff()) m = x[i];
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float av = fabsf(x[i]);
+        if (av > m && av < __builtin_inff()) m = av;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+
+// {s, 1/s} from the bound  max_f (|W1u_f|_1 mu + |b1_f|) + max_f |W1i_f|_1 mi  on p + q (tower_shared.h).  One block of H1 threads:
+// thread f owns output feature f of layer 1 (W1 [H1, 2 dm] row-major, user half first).
+__global__ __launch_bounds__(H1) void l1scale_kernel(const float* __restrict__ W1, const float* __restrict__ b1, int dm,
+                                                      const unsigned int* maxima, float* out)
+{
+    __shared__ float s_a[H1], s_c[H1];
+    const int f = threadIdx.x;
+    const float mu = __uint_as_float(maxima[0]), mi = __uint_as_float(maxima[1]);
+    float lu = 0.f, li = 0.f;
+    for (int k = 0; k < dm; ++k) { lu += fabsf(W1[(int64_t)f * 2 * dm + k]); li += fabsf(W1[(int64_t)f * 2 * dm + dm + k]); }
+    const float a = lu * mu + fabsf(b1[f]), c = li * mi;
+    s_a[f] = (a == a && a < __builtin_inff()) ? a : 0.f;
+    s_c[f] = (c == c && c < __builtin_inff()) ? c : 0.f;
+    __syncthreads();
+    if (f == 0) {
+        float ma = 0.f, mc = 0.f;
+        for (int i = 0; i < H1; ++i) { ma = fmaxf(ma, s_a[i]); mc = fmaxf(mc, s_c[i]); }
+        const Layer1Scale sc = layer1_scale_for((ma + mc) * 1.001f);      // margin for the roundings of this estimate
+        out[0] = sc.s;
+        out[1] = sc.inv;
+    }
 }
 
 template <int G, bool L3>
@@ -868,7 +893,7 @@ int launch_tile_topk_t(const TileArgs& a, const TopkFuse& f, hipStream_t s)
     return RECO_OK;
 }
 
-template <int G, bool L3, bool BIG>
+template <int G, bool L3, bool BIG, bool CLAMP>
 int launch_pairs_tb(const PairArgs& a, hipStream_t s)
 {
     // 8 waves per workgroup when their half-row staging areas fit next to the image (G <= 32: 148 KB), else 4 (six waves of the
@@ -877,10 +902,10 @@ int launch_pairs_tb(const PairArgs& a, hipStream_t s)
     constexpr size_t lds = (size_t)(LDS_IMG_SIZE<L3> + WAVES * (32 * HS + (G > 0 ? 32 * (G + 4) : 0))) * sizeof(float);
     static_assert(lds <= 160 * 1024, "pair kernel LDS budget");
     static bool attr[RECO_MAX_DEVICES] = {};
-    if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&tower_pairs_kernel<G, L3, WAVES, BIG>), lds, attr)) return rc;
+    if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&tower_pairs_kernel<G, L3, WAVES, BIG, CLAMP>), lds, attr)) return rc;
     const int64_t nchunks = ceil_div64(a.B, 32 * WAVES);
     const unsigned grid = (unsigned)(nchunks < 256 ? nchunks : 256);   // persistent: one workgroup per CU
-    hipLaunchKernelGGL((tower_pairs_kernel<G, L3, WAVES, BIG>), dim3(grid), dim3(64 * WAVES), lds, s, a);
+    hipLaunchKernelGGL((tower_pairs_kernel<G, L3, WAVES, BIG, CLAMP>), dim3(grid), dim3(64 * WAVES), lds, s, a);
     RECO_CHECK_LAUNCH();
     return RECO_OK;
 }
@@ -890,7 +915,8 @@ int launch_pairs_t(const PairArgs& a, hipStream_t s)
 {
     // 32-bit row offsets (saddr loads) whenever every table is under 2^23 rows; 64-bit offsets otherwise (tower_shared.h)
     const bool big = a.n_users >= (1ll << 23) || a.n_items >= (1ll << 23);
-    return big ? launch_pairs_tb<G, L3, true>(a, s) : launch_pairs_tb<G, L3, false>(a, s);
+    if (a.l1) return big ? launch_pairs_tb<G, L3, true, true>(a, s) : launch_pairs_tb<G, L3, false, true>(a, s);
+    return big ? launch_pairs_tb<G, L3, true, false>(a, s) : launch_pairs_tb<G, L3, false, false>(a, s);
 }
 
 }  // namespace
@@ -911,12 +937,11 @@ int tower_launch_tile(int G, int has_l3, const float* img, const float* P, const
                       const float* EUg, const float* EIg, const int64_t* users, const int64_t* cands,
                       int64_t user_base, int64_t n_users, int64_t n_items, int64_t U, int64_t N,
                       float* out, int64_t ld_out, float bp, int act, float lo, float hi, int32_t* oob,
-                      unsigned int* next_tile, const float* pmax, const float* qmax, hipStream_t s)
+                      unsigned int* next_tile, const float* l1, hipStream_t s)
 {
     if (U <= 0 || N <= 0) return RECO_OK;
-    RECO_REQUIRE(pmax && qmax, "tower tile kernel: the layer-1 maxima of this call are missing");
-    TileArgs a{img, P, Q, EUg, EIg, users, cands, user_base, n_users, n_items, U, N, out, ld_out, bp, act, lo, hi, oob, next_tile,
-               pmax, qmax};
+    RECO_REQUIRE(l1, "tower tile kernel: the layer-1 scale is missing");
+    TileArgs a{img, P, Q, EUg, EIg, users, cands, user_base, n_users, n_items, U, N, out, ld_out, bp, act, lo, hi, oob, next_tile, l1};
     if (G == 32 && has_l3) return launch_tile_t<32, true>(a, s);
     if (G == 0 && has_l3) return launch_tile_t<0, true>(a, s);
     if (G == 64 && !has_l3) return launch_tile_t<64, false>(a, s);
@@ -927,10 +952,10 @@ int tower_launch_tile(int G, int has_l3, const float* img, const float* P, const
 int tower_launch_pairs(int G, int has_l3, const float* img, const float* P, const float* Q,
                        const float* EUg, const float* EIg, const int64_t* user, const int64_t* item,
                        int64_t n_users, int64_t n_items, int64_t B, float* out, float bp, int act,
-                       float lo, float hi, int32_t* oob, hipStream_t s)
+                       float lo, float hi, int32_t* oob, const float* l1, hipStream_t s)
 {
-    if (B <= 0) return RECO_OK;
-    PairArgs a{img, P, Q, EUg, EIg, user, item, n_users, n_items, B, out, bp, act, lo, hi, oob};
+    if (B <= 0) return RECO_OK;      // l1 null: P and Q are unscaled, layer 1 is add + max
+    PairArgs a{img, P, Q, EUg, EIg, user, item, n_users, n_items, B, out, bp, act, lo, hi, oob, l1};
     if (G == 32 && has_l3) return launch_pairs_t<32, true>(a, s);
     if (G == 0 && has_l3) return launch_pairs_t<0, true>(a, s);
     if (G == 64 && !has_l3) return launch_pairs_t<64, false>(a, s);
@@ -966,12 +991,22 @@ int gmf_launch_tile(const float* EUg, const float* EIg, const float* wp, const i
     return RECO_OK;
 }
 
-// *out (zeroed by the caller, on this stream) = bit pattern of the largest finite positive element of x[0, n)
-int tower_launch_posmax(const float* x, int64_t n, unsigned int* out, hipStream_t s)
+// out[0..1] = {s, 1/s} for layer 1 over the given user / item rows (tower_shared.h); scratch: 2 words, cleared here.
+// Three small launches on `s`; nothing is read back.
+int tower_launch_l1scale(const float* W1, const float* b1, int dm, const float* u_rows, int64_t u_elems,
+                         const float* i_rows, int64_t i_elems, unsigned int* scratch, float* out, hipStream_t s)
 {
-    if (n <= 0) return RECO_OK;
-    const int64_t blocks = ceil_div64(n, 256 * 16);
-    hipLaunchKernelGGL(posmax_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, s, x, n, out);
+    RECO_CHECK_HIP(hipMemsetAsync(scratch, 0, 2 * sizeof(unsigned int), s));
+    const int64_t elems[2] = {u_elems, i_elems};
+    const float* rows[2] = {u_rows, i_rows};
+    for (int side = 0; side < 2; ++side) {
+        if (elems[side] <= 0) continue;
+        const int64_t blocks = ceil_div64(elems[side], 256 * 16);
+        hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, s, rows[side], elems[side],
+                           scratch + side);
+        RECO_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(l1scale_kernel, dim3(1), dim3(H1), 0, s, W1, b1, dm, scratch, out);
     RECO_CHECK_LAUNCH();
     return RECO_OK;
 }
@@ -990,14 +1025,13 @@ int tower_launch_tile_topk(int G, int has_l3, const float* img, const float* P, 
                            int64_t user_base, int64_t n_users, int64_t n_items, int64_t U, int64_t N,
                            float bp, int act, float lo, float hi, int32_t* oob,
                            int k, int v_max, unsigned int* counters, unsigned long long* partial,
-                           const float* pmax, const float* qmax, hipStream_t s)
+                           const float* l1, hipStream_t s)
 {
     if (U <= 0 || N <= 0) return RECO_OK;
-    RECO_REQUIRE(pmax && qmax, "fused top-k tile kernel: the layer-1 maxima of this call are missing");
+    RECO_REQUIRE(l1, "fused top-k tile kernel: the layer-1 scale is missing");
     RECO_REQUIRE(k >= 1 && k <= 128 && v_max >= 1 && v_max <= 1024, "fused top-k: k=%d / v_max=%d out of range", k, v_max);
     RECO_REQUIRE(N < (1ll << 31) && ceil_div64(U, 16) < (1ll << 21), "fused top-k: problem too large for one launch");
-    TileArgs a{img, P, Q, EUg, EIg, users, cands, user_base, n_users, n_items, U, N, nullptr, 0, bp, act, lo, hi, oob, nullptr,
-               pmax, qmax};
+    TileArgs a{img, P, Q, EUg, EIg, users, cands, user_base, n_users, n_items, U, N, nullptr, 0, bp, act, lo, hi, oob, nullptr, l1};
     const int64_t blocks = ceil_div64(U, tower_tile_users_per_block(G));
     TopkFuse f{k, v_max, counters, counters + 64, counters + 64 + blocks, partial};
     if (k <= 64) {

@@ -98,25 +98,28 @@ struct TileArgs {
     int32_t* oob;
     unsigned int* next_tile;   // work queue: tiles beyond the first gridDim.x are handed out through this counter (zeroed
                                // before the launch); null = static round-robin
-    const float* pmax;         // exact tile kernels: largest finite positive element of the P rows / of the Q rows of this call
-    const float* qmax;         // (device words written by posmax_kernel); they fix the layer-1 scale, see layer1_scale()
+    const float* l1;           // exact kernels: device words {s, 1/s}, the power-of-two scale P and Q were written with (below)
 };
 
 // ---- layer 1 as ONE instruction per element -------------------------------------------------------------------------------
 // x1 = relu(p + q) is an add and a max, 128 of the ~236 VALU instructions a wave issues per 160 MFMAs -- and beside f32 MFMAs
 // every VALU instruction costs MFMA issue time.  v_add_f32 with the CLAMP modifier is add + clamp to [0, 1] in one instruction,
-// and clamp IS relu when nothing exceeds 1.  So the tile kernels work on s * x1 with s a power of two chosen per call such
-// that s * (max P + max Q) < 1: P and Q are multiplied by s when they are staged into LDS, the biases b2 / b3 by s and the MLP
-// half of the predict weights by 1/s when the weight image is copied into LDS.  Scaling by a power of two commutes with every
-// rounding on the way (relu commutes with it too), so the scores are bit-identical to the unscaled computation, short of
-// terms ~2^-100 below the call's largest activation underflowing.  Measured: cfg2 tile kernel 3.245 -> 3.155 ms.
-// Non-finite P / Q elements are left out of the maxima: a pair that touches one gets a finite but meaningless score where the
-// reference has inf / NaN; every other pair is unaffected.
+// and clamp IS relu when nothing exceeds 1.  So the exact kernels work on s * x1 with s a power of two such that
+// s * (p + q) < 1 for every pair the handle (or the call) can form: the projection GEMMs write P and Q multiplied by s
+// (gemm.hip out_scale), the biases b2 / b3 are multiplied by s and the MLP half of the predict weights by 1/s when the weight
+// image is copied into LDS.  Scaling by a power of two commutes with every rounding on the way (and with relu), so the scores
+// are bit-identical to the unscaled computation, short of terms ~2^-100 below the largest possible activation underflowing.
+// s comes from a bound, not from the data of one call: |p_f| <= |W1u_f|_1 max|user rows| + |b1_f|, |q_f| <= |W1i_f|_1 max|item
+// rows| (l1scale_kernel: once per handle over its tables, per call when the rows are handed in).  Non-finite table entries are
+// left out of the maxima: a pair that touches one gets a finite but meaningless score where the reference has inf / NaN;
+// every other pair is unaffected.  Measured: cfg2 tile kernel 3.245 -> 3.155 ms with the add alone.
 struct Layer1Scale { float s, inv; };
 
-__device__ __forceinline__ Layer1Scale layer1_scale(const float* pmax, const float* qmax)
+__device__ __forceinline__ Layer1Scale layer1_scale(const float* l1) { return Layer1Scale{l1[0], l1[1]}; }
+
+// {s, 1/s} for a bound b >= 0 on p + q: s = 2^-k with 2^k > b
+__device__ __forceinline__ Layer1Scale layer1_scale_for(float b)
 {
-    const float b = pmax[0] + qmax[0];                       // both >= 0 and finite by construction
     int e = (int)((__float_as_uint(b) >> 23) & 255u);        // b < 2^(e - 126)
     int se = 253 - e;                                        // biased exponent of s = 2^-(e - 126)
     se = se < 1 ? 1 : (se > 253 ? 253 : se);
@@ -223,6 +226,7 @@ struct PairArgs {
     int act;
     float lo, hi;
     int32_t* oob;
+    const float* l1;       // exact kernel: device words {s, 1/s} (TileArgs::l1)
 };
 
 // Per wave: 32 pairs at a time, fully wave-private (no workgroup barrier in the loop).  The P/Q/GMF rows of the NEXT 32
@@ -385,12 +389,13 @@ __device__ __forceinline__ void pair_load_half(const PairArgs& a, int my_u, int 
     }
 }
 
+template <bool CLAMP>
 __device__ __forceinline__ void pair_store_half(float* s_x, int lane, const f32x4* p, const f32x4* q)
 {
     const int c = lane & 15, r = lane >> 4;
 #pragma unroll
-    for (int it = 0; it < 8; ++it)
-        *reinterpret_cast<f32x4*>(s_x + (4 * it + r) * HS + 4 * c) = relu4(p[it] + q[it]);
+    for (int it = 0; it < 8; ++it)     // CLAMP: = s * relu(p + q), P / Q pre-scaled
+        *reinterpret_cast<f32x4*>(s_x + (4 * it + r) * HS + 4 * c) = CLAMP ? add_clamp4(p[it], q[it]) : relu4(p[it] + q[it]);
 }
 
 template <int G, bool BIG>
