@@ -24,6 +24,11 @@
  *     belongs to the call, not to a handle: concurrent callers never see each other's ids;
  *   - NaN conventions: ReLU is max on the raw bits (one VALU instruction beside the MFMAs): a NaN with the sign bit set
  *     becomes +0 where torch.relu would propagate it; NaN inputs are outside the parity contract;
+ *   - the exact tower kernels evaluate layer 1 on activations multiplied by a power of two s (one clamped add per element instead
+ *     of add + max; scores keep their bits: DESIGN.md section 3 K-b).  s is derived in reco_tower_create from a bound over the
+ *     handle's MLP tables and first-layer weights (per call for the *_rows forms), so -- like the cached projections -- it
+ *     belongs to the table contents at creation: rebuild the handle after changing them.  Non-finite table entries are left
+ *     out of that bound: a pair that touches one gets a finite, meaningless score where the reference has inf / NaN;
  *   - nothing allocates except *_create (the packed-model handles) -- scratch memory is
  *     brought in by the caller as `ws` / `ws_bytes` (query the size with *_workspace_bytes).
  */

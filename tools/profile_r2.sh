@@ -24,11 +24,14 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 timeout -s KILL 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d "$OUT/bench_mfma" -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-split --no-cfg5 > "$OUT/bench_mfma.json" 2> "$OUT/bench_mfma.err"
 echo "bench mfma done"
+timeout -s KILL 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d "$OUT/bench_insts" -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-split --no-cfg5 > "$OUT/bench_insts.json" 2> "$OUT/bench_insts.err"
+echo "bench instruction counts done"
 cd "$ROOT"
 python3 tools/kernel_trace_summary.py "$OUT/kb_trace" > "$OUT/kernel_bench_trace.json"
 python3 tools/kernel_trace_summary.py "$OUT/bench_trace" > "$OUT/bench_trace.json"
 python3 tools/pmc_summary.py "$OUT/kb_fetch" "$OUT/kb_write" > "$OUT/gather_hbm_traffic.json"
 python3 tools/pmc_summary.py "$OUT/bench_FETCH_SIZE" "$OUT/bench_WRITE_SIZE" "$OUT/bench_mfma" > "$OUT/bench_hbm_traffic.json"
+python3 tools/pmc_summary.py "$OUT/bench_insts" > "$OUT/bench_sq_insts.json"
 find "$OUT" -name "*stats*.csv" | head
 # raw traces are large: keep the summaries and the stats tables only
 find "$OUT" -name "*kernel_trace.csv" -size +2M -delete
