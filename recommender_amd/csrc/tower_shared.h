@@ -122,7 +122,9 @@ __device__ __forceinline__ Layer1Scale layer1_scale_for(float b)
 {
     int e = (int)((__float_as_uint(b) >> 23) & 255u);        // b < 2^(e - 126)
     int se = 253 - e;                                        // biased exponent of s = 2^-(e - 126)
-    se = se < 1 ? 1 : (se > 253 ? 253 : se);
+    // s <= 2^24: a smaller s than the bound allows is always safe for the clamp, and tables of zeros / 1e-30 must not push
+    // s * b2 to overflow or w_predict / s into the denormals
+    se = se < 1 ? 1 : (se > 127 + 24 ? 127 + 24 : se);
     return Layer1Scale{__uint_as_float((unsigned)se << 23), __uint_as_float((unsigned)(254 - se) << 23)};
 }
 

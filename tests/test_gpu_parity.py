@@ -530,9 +530,8 @@ def test_topk_many_short_rows_lane_kernel():
 
 @pytest.mark.parametrize("scale", [1e-6, 0.01, 1.0, 25.0, 3000.0])
 def test_tile_kernels_equal_the_pair_kernel_bit_for_bit_at_any_embedding_scale(scale):
-    """The tile kernels compute layer 1 as ONE clamped add per element on activations scaled by a per-call power of two
-    (tower_shared.h layer1_scale); the pair-list kernel computes relu(P + Q) unscaled.  Scaling by a power of two commutes with
-    every rounding, so score_matrix / score_topk must reproduce score_pairs to the bit whatever the size of the embeddings
+    """Tile kernels and pair-list kernel share the MFMA body and the clamped layer 1 (tower_shared.h layer1_scale), so
+    score_matrix / score_topk must reproduce score_pairs to the bit whatever the size of the embeddings
     (MLP-only model; with a GMF half the two kernels round its products in a different order and agree to ~1e-7)."""
     from recommender_amd.helpers import NCF
     torch.manual_seed(21)
@@ -591,3 +590,34 @@ def test_scores_do_not_depend_on_the_layer1_scale(name):
         ia, va = ta.score_topk(users, 9, fused=fused)
         ib, vb = tb.score_topk(users, 9, fused=fused)
         assert torch.equal(ia, ib) and torch.equal(va.view(torch.int32), vb.view(torch.int32))
+
+
+@pytest.mark.parametrize("emb", [0.0, 1e-30, 1e-12, 1e12])
+@pytest.mark.parametrize("name", ["NeuMF-end", "MLP"])
+def test_degenerate_embedding_magnitudes_against_the_oracle(name, emb):
+    """The layer-1 scale s is a power of two from a bound over the tables: all-zero tables (bound = |b1|, or 0), embeddings of
+    1e-30 (s is capped at 2^24 so that s * b2 cannot overflow nor w_predict / s go denormal) and of 1e12 (s ~ 2^-50) must still
+    give the oracle's scores: every form, fp32 gate relative to the largest score."""
+    from recommender_amd.helpers import NCF
+    torch.manual_seed(5)
+    m = NCF(40, 70, 32, 3, 0.0, name).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "embed" in n:
+                p.mul_(100.0 * emb)                       # reference init: std 0.01
+            elif n.endswith("bias"):
+                p.copy_(torch.randn_like(p) * (0.0 if emb == 0.0 and "MLP_layers.0" in n else 0.7))
+    sd = {k: v.numpy() for k, v in m.state_dict().items()}
+    uu, ii = np.meshgrid(np.arange(40), np.arange(70), indexing="ij")
+    want = O.ncf_forward(sd, uu.reshape(-1), ii.reshape(-1), dtype=np.float64).reshape(40, 70)
+    assert np.isfinite(want).all()
+    atol = 1e-6 * max(1.0, float(np.abs(want).max()))
+    t = m.cuda()._tower(torch.device("cuda", 0))
+    pairs = t.score_pairs(torch.from_numpy(uu.reshape(-1)).cuda(), torch.from_numpy(ii.reshape(-1)).cuda()).view(40, 70)
+    full = t.score_matrix()
+    assert_close(pairs.cpu().numpy(), want, rtol=1e-5, atol=atol, what="pairs %s %g" % (name, emb))
+    assert_close(full.cpu().numpy(), want, rtol=1e-5, atol=atol, what="matrix %s %g" % (name, emb))
+    for fused in (False, True):
+        ids, vals = t.score_topk(None, 5, fused=fused)
+        oid, oval = O.topk_rows(full.cpu().numpy(), 5)
+        assert np.array_equal(ids.cpu().numpy(), oid) and np.array_equal(vals.cpu().numpy().view(np.uint32), oval.view(np.uint32))
