@@ -28,7 +28,9 @@
  *     of add + max; scores keep their bits: DESIGN.md section 3 K-b).  s is derived in reco_tower_create from a bound over the
  *     handle's MLP tables and first-layer weights (per call for the *_rows forms), so -- like the cached projections -- it
  *     belongs to the table contents at creation: rebuild the handle after changing them.  Non-finite table entries are left
- *     out of that bound: a pair that touches one gets a finite, meaningless score where the reference has inf / NaN;
+ *     out of that bound, and s is kept within [2^-80, 2^24]: a pair that touches a non-finite entry, or whose layer-1
+ *     pre-activation exceeds 2^80, gets a finite, meaningless score where the reference has inf / NaN / a huge value; every
+ *     other pair is unaffected by such rows;
  *   - nothing allocates except *_create (the packed-model handles) -- scratch memory is
  *     brought in by the caller as `ws` / `ws_bytes` (query the size with *_workspace_bytes).
  */

@@ -124,7 +124,10 @@ __device__ __forceinline__ Layer1Scale layer1_scale_for(float b)
     int se = 253 - e;                                        // biased exponent of s = 2^-(e - 126)
     // s <= 2^24: a smaller s than the bound allows is always safe for the clamp, and tables of zeros / 1e-30 must not push
     // s * b2 to overflow or w_predict / s into the denormals
-    se = se < 1 ? 1 : (se > 127 + 24 ? 127 + 24 : se);
+    // s >= 2^-80: one absurd row (|p + q| beyond 2^80, i.e. 1e24) must not push every OTHER row's scaled activations, s * b2 and
+    // their products towards the denormals; such a row's own activations saturate at 2^80 instead (a finite, meaningless score
+    // for the pairs that touch it, like the non-finite entries above; every other pair stays exact)
+    se = se < 127 - 80 ? 127 - 80 : (se > 127 + 24 ? 127 + 24 : se);
     return Layer1Scale{__uint_as_float((unsigned)se << 23), __uint_as_float((unsigned)(254 - se) << 23)};
 }
 

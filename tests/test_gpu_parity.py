@@ -621,3 +621,41 @@ def test_degenerate_embedding_magnitudes_against_the_oracle(name, emb):
         ids, vals = t.score_topk(None, 5, fused=fused)
         oid, oval = O.topk_rows(full.cpu().numpy(), 5)
         assert np.array_equal(ids.cpu().numpy(), oid) and np.array_equal(vals.cpu().numpy().view(np.uint32), oval.view(np.uint32))
+
+
+def test_an_absurd_or_non_finite_row_does_not_disturb_the_other_rows():
+    """One user row of 1e36 and one holding inf / NaN.  The first one's layer-1 pre-activations (~2^122) are beyond the 2^80 the
+    scale admits -- following it, s = 2^-123 would put the other rows' s * b2 into the denormals; the scale is floored at 2^-80
+    instead.  Their own pairs get finite scores without meaning (header conventions); every other user keeps its scores bit for
+    bit."""
+    from recommender_amd.helpers import NCF
+    torch.manual_seed(44)
+    a = NCF(90, 130, 32, 3, 0.0, "NeuMF-end").eval()
+    with torch.no_grad():
+        for n, p in a.named_parameters():
+            if "embed" in n:
+                p.mul_(30.0)
+    b = NCF(92, 130, 32, 3, 0.0, "NeuMF-end").eval()
+    sd = a.state_dict()
+    with torch.no_grad():
+        for k, v in b.state_dict().items():
+            if k.startswith("embed_user"):
+                v[:90] = sd[k]
+                v[90] = 1e36
+                v[91] = sd[k][1]
+                v[91, 0] = float("inf"); v[91, 1] = float("nan")
+            else:
+                v.copy_(sd[k])
+    ta, tb = a.cuda()._tower(torch.device("cuda", 0)), b.cuda()._tower(torch.device("cuda", 0))
+    users = torch.arange(90).cuda()
+    assert torch.equal(ta.score_matrix(users).view(torch.int32), tb.score_matrix(users).view(torch.int32))
+    uu, ii = torch.meshgrid(torch.arange(90), torch.arange(130), indexing="ij")
+    pa = ta.score_pairs(uu.reshape(-1).cuda(), ii.reshape(-1).cuda())
+    pb = tb.score_pairs(uu.reshape(-1).cuda(), ii.reshape(-1).cuda())
+    assert torch.equal(pa.view(torch.int32), pb.view(torch.int32))
+    # and against the oracle (the 2^-80 scale must not cost the ordinary rows any accuracy)
+    sda = {k: v.cpu().numpy() for k, v in a.state_dict().items()}
+    want = O.ncf_forward(sda, uu.reshape(-1).numpy(), ii.reshape(-1).numpy(), dtype=np.float64)
+    assert_close(pb.cpu().numpy(), want, rtol=1e-5, atol=1e-6 * max(1.0, float(np.abs(want).max())), what="ordinary rows beside an outlier")
+    out = tb.score_matrix(torch.tensor([90]).cuda())
+    assert out.shape == (1, 130)                     # the outlier's own scores: whatever they are, the call completes
