@@ -119,3 +119,41 @@ def test_noalloc_topk_rejects_what_does_not_fit_and_launches_nothing():
     assert L.reco_tower_score_topk_noalloc(tower._h, None, 0, 4, None, 2000, 0, None, 0, _p(ids), _p(vals), None, st) == _lib.EINVAL
     assert L.reco_tower_score_topk_noalloc(tower._h, None, 0, 4, None, 2000, 10, None, 0, None, None, None, st) == _lib.EINVAL
     assert L.reco_tower_score_topk_noalloc(None, None, 0, 4, None, 2000, 10, None, 0, _p(ids), _p(vals), None, st) == _lib.EINVAL
+
+
+def test_noalloc_topk_inside_a_captured_hip_graph():
+    """The callers the entry point exists for: under stream capture nothing may allocate.  One call is captured into a HIP
+    graph (torch.cuda.graph on a side stream), replayed twice on new user lists, and compared bit for bit with the plain
+    workspace form on the same inputs."""
+    from recommender_amd import _lib
+    L = _lib.lib()
+    _, tower = _tower(700, 2000, 3)
+    dev = tower.device
+    U, N, k = 300, 2000, 20
+    g = torch.Generator(device="cpu").manual_seed(9)
+    users = torch.randint(0, 700, (U,), generator=g).to(dev)
+    ids = torch.full((U, k), -7, dtype=torch.int32, device=dev)
+    vals = torch.zeros((U, k), dtype=torch.float32, device=dev)
+
+    def call(stream):
+        return L.reco_tower_score_topk_noalloc(tower._h, _p(users), 0, U, None, N, k, None, 0, _p(ids), _p(vals), None,
+                                               ctypes.c_void_p(stream.cuda_stream))
+
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        _lib.check(call(side))                      # warm-up outside the capture: first launches set kernel attributes
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        rc = call(torch.cuda.current_stream(dev))
+    assert rc == 0, L.reco_last_error()
+    for trial in range(2):
+        users.copy_(torch.randint(0, 700, (U,), generator=g))
+        ids.fill_(-7)
+        torch.cuda.synchronize(dev)
+        graph.replay()
+        torch.cuda.synchronize(dev)
+        want_ids, want_vals = tower.score_topk(users, k)
+        assert np.array_equal(ids.cpu().numpy(), want_ids.cpu().numpy()), trial
+        assert np.array_equal(vals.cpu().numpy().view(np.uint32), want_vals.cpu().numpy().view(np.uint32)), trial
