@@ -1,5 +1,7 @@
 """A/B in one process, same clocks: reco_tower_score_topk_fused (one kernel scores and selects, no score rows in memory)
-against reco_tower_score_topk (score rows in the workspace + the stand-alone select).  One JSON line per shape."""
+against reco_tower_score_topk (score rows in the workspace + the stand-alone select).  One JSON line per shape.
+NOTE: for mask-free calls whose score rows need several user chunks reco_tower_score_topk takes the fused form by itself
+(api.hip fused_topk_preferred), so for those shapes both legs run the same kernel."""
 import json
 import os
 import sys
