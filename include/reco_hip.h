@@ -217,7 +217,7 @@ int reco_tower_score_matrix(reco_tower_t* t, const int64_t* users, int64_t user_
  *   score = score*(1-seen) - seen*1e10.
  * out_ids [U,k] int32 = POSITIONS in the candidate list (== item ids when cands is NULL),
  * out_scores [U,k]; order: descending score, ascending position among equals.
- * k <= 128.  Mask-free calls on the exact MFMA tower whose score rows exceed one 1 GiB user chunk run as
+ * k <= 128.  Mask-free calls on the exact MFMA tower (NeuMF / MLP shapes) whose score rows exceed one 1 GiB user chunk run as
  * reco_tower_score_topk_fused below (same results, one launch instead of one per chunk); the workspace size covers both. */
 size_t reco_tower_topk_workspace_bytes(int64_t U, int64_t N, int k);
 int reco_tower_score_topk(reco_tower_t* t, const int64_t* users, int64_t user_base, int64_t U,
@@ -232,9 +232,10 @@ int reco_tower_score_topk(reco_tower_t* t, const int64_t* users, int64_t user_ba
  * replaces the same reference lines (inference_engine.py:162-166; SURVEY section 7 "the score row never reaches HBM").
  * Trade (measured): HBM writes per launch fall from the score rows (85 MB at 6038 x 3533) to the lists and
  * the workspace from U x N floats to a few lists per user; where the score rows fit ONE user chunk (1 GiB) the two-kernel form
- * is 0-5 % faster (the list upkeep shares the SIMDs with the MFMAs; a request for a handful of users over a long catalog loses
- * more), where they do not (1,024 x 1M: five chunks) this form is 2 % faster -- and reco_tower_score_topk takes it by itself
- * for such mask-free calls.  This entry point forces it for any shape.  The workspace size depends on the handle (its user-block size). */
+ * is 1-6 % faster (the list upkeep shares the SIMDs with the MFMAs; a request for a handful of users over a long catalog loses
+ * more; the Hybrid head shape loses 8-11 % everywhere), where they do not (1,024 x 1M: five chunks) this form is level or ahead
+ * at half the workspace -- and reco_tower_score_topk takes it by itself for such mask-free calls on the NeuMF / MLP shapes.
+ * This entry point forces it for any shape.  The workspace size depends on the handle (its user-block size). */
 size_t reco_tower_topk_fused_workspace_bytes(const reco_tower_t* t, int64_t U, int64_t N, int k);
 int reco_tower_score_topk_fused(reco_tower_t* t, const int64_t* users, int64_t user_base, int64_t U,
                                 const int64_t* cands, int64_t N, int k,

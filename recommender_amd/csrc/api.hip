@@ -556,9 +556,12 @@ static bool fused_topk_available(const reco_tower* t) { return t->mfma && !t->im
 // reco_tower_score_topk itself takes the fused form where it measured faster: mask-free calls whose score rows would not fit one
 // user chunk (1,024 x 1M, k = 100: 157.6 -> 154.3 ms, five tile launches + five scans against one launch + a merge; where one
 // chunk suffices the two-kernel form is 0-5 % ahead, DESIGN section 3, fused kernel).
+// Not for the Hybrid head shape (GMF width 64): its fused kernel needs ~210 VGPRs, spills 39-45 of them at three waves per SIMD
+// and runs 8-11 % behind the two-kernel form on every shape measured (tools/hybrid_fused_ab.py; at 512 threads x 16 users it
+// does not spill and is still 5-15 % behind).  reco_tower_score_topk_fused still forces it.
 static bool fused_topk_preferred(const reco_tower* t, const uint8_t* exclude, int64_t U, int64_t N)
 {
-    return fused_topk_available(t) && !exclude && U > default_chunk(U, N);
+    return fused_topk_available(t) && t->G <= 32 && !exclude && U > default_chunk(U, N);
 }
 
 extern "C" size_t reco_tower_topk_workspace_bytes(int64_t U, int64_t N, int k)
