@@ -69,11 +69,11 @@ class NCFInferenceEngine:
         if len(item_ids) <= 128:           # one fused call: the stable descending sort IS the top-n select's order
             device = self.model._compute_device()
             buf, ids, vals = packed_topk_buffers(1, len(item_ids), device)
-            self.model.score_topk(torch.tensor([user_id]), len(item_ids), cands, check_ids=False, out=(ids, vals))
+            self.model.score_topk((int(user_id), 1), len(item_ids), cands, check_ids=False, out=(ids, vals))
             host = buf.cpu()
             order = host[0, 0].numpy(); vals = host[1, 0].view(torch.float32).numpy()
         else:                              # long lists: tile path + stable descending sort on the host
-            sc = self.model.score_matrix(torch.tensor([user_id]), cands)[0].cpu().numpy()
+            sc = self.model.score_matrix((int(user_id), 1), cands)[0].cpu().numpy()
             order = np.argsort(-sc, kind="stable"); vals = sc[order]
         return [(int(item_ids[j]), float(v)) for j, v in zip(order, vals)]
 
@@ -95,14 +95,14 @@ class NCFInferenceEngine:
         if k <= 0:
             return []                                                          # scores[...][:0]
         if k > 128:                        # beyond the schema's k <= 100 (schemas.py:61) and the wavefront select: host sort
-            sc = self.model.score_matrix(torch.tensor([user_id]), cands)[0].cpu().numpy()
+            sc = self.model.score_matrix((int(user_id), 1), cands)[0].cpu().numpy()
             order = np.argsort(-sc, kind="stable")[:k]
             ids = order if cands is None else cands.numpy()[order]
             return [(int(i), float(v)) for i, v in zip(ids, sc[order])]
         # ids were validated above, so the kernel-side range report (a sync) is skipped; ids and scores come back in ONE copy
         device = self.model._compute_device()
         buf, ids, vals = packed_topk_buffers(1, k, device)
-        self.model.score_topk(torch.tensor([user_id]), k, cands, check_ids=False, out=(ids, vals))
+        self.model.score_topk((int(user_id), 1), k, cands, check_ids=False, out=(ids, vals))
         host = buf.cpu()
         ids = host[0, 0].numpy(); vals = host[1, 0].view(torch.float32).numpy()
         if cands is not None:
