@@ -51,3 +51,28 @@ def ndcg_multi(gt_items, pred_items):
             dcg += 1.0 / np.log2(rank + 2)
     ideal = sum(1.0 / np.log2(r + 2) for r in range(min(len(gt), len(pred_items))))
     return dcg / ideal if ideal else 0.0
+
+
+def multi_gt_metrics_batch(top_ids, test_matrix):
+    """hit_multi / ndcg_multi for every user at once: top_ids [users, K], test_matrix [users, items] (> 0 = ground truth) ->
+    (hr float64[users], ndcg float64[users], has_gt bool[users]).
+
+    Same numbers as the per-user loops, bit for bit: the rank weights come from the same scalar expression, DCG and the
+    ideal DCG are accumulated in rank order (adding 0.0 where a rank misses changes nothing), and only the loop over users
+    is gone (6,040 Python iterations with set lookups were ~50 ms beside 3 ms of kernels)."""
+    top = np.asarray(top_ids).astype(np.int64, copy=False)
+    gt_mask = np.asarray(test_matrix) > 0
+    users, K = top.shape
+    n_gt = gt_mask.sum(axis=1)
+    hits = gt_mask[np.arange(users)[:, None], top]
+    w = [1.0 / np.log2(r + 2) for r in range(K)]
+    dcg = np.zeros(users, np.float64)
+    ideal_by_count = np.zeros(K + 1, np.float64)
+    acc = 0
+    for r in range(K):
+        dcg += np.where(hits[:, r], w[r], 0.0)
+        acc = acc + w[r]
+        ideal_by_count[r + 1] = acc
+    ideal = ideal_by_count[np.minimum(n_gt, K)]
+    nd = np.divide(dcg, ideal, out=np.zeros(users, np.float64), where=ideal > 0)
+    return hits.any(axis=1).astype(np.float64), nd, n_gt > 0
