@@ -72,3 +72,40 @@ def test_test_negative_never_evaluates_file_content(tmp_path):
     empty.write_text("")
     u, it = D.read_test_negative(empty)
     assert u.shape == (0,) and it.shape[0] == 0
+
+
+def test_test_negative_fast_path_equals_the_line_reader(tmp_path, monkeypatch):
+    """The one-pass reader of well-formed files returns exactly what the line-by-line reader returns, and steps aside (None)
+    for everything unusual so that the line reader decides: empty fields, a trailing blank line and what follows it, spaces
+    inside the '(u, i)' field, a token that is not an integer."""
+    rng = np.random.default_rng(2)
+    users = rng.integers(0, 6040, 300); items = rng.integers(0, 3706, (300, 100))
+    good = tmp_path / "good.test.negative"
+    D.write_test_negative(good, users, items)
+    txt = open(good).read()
+    fast = D._read_test_negative_fast(txt)
+    assert fast is not None and fast[0].dtype == np.int32 and fast[1].dtype == np.int32
+    monkeypatch.setattr(D, "_read_test_negative_fast", lambda t: None)
+    slow = D.read_test_negative(good)
+    monkeypatch.undo()
+    assert np.array_equal(fast[0], slow[0]) and np.array_equal(fast[1], slow[1])
+    assert np.array_equal(slow[0], users) and np.array_equal(slow[1], items)
+    both = D.read_test_negative(good)
+    assert np.array_equal(both[1], items)
+    # stops at the first empty line, like the reference
+    cut = tmp_path / "cut.test.negative"
+    cut.write_text("(1, 2)\t3\t4\n(5, 6)\t7\t8\n\n(9, 9)\t9\t9\n")
+    u, it = D.read_test_negative(cut)
+    assert u.tolist() == [1, 5] and it.tolist() == [[2, 3, 4], [6, 7, 8]]
+    # unusual but valid for the line reader: the fast path declines, the result is the line reader's
+    for text, want in [("(1, 2)\t3\t\t4\n", [[2, 3, 4]]), ("( 1 ,2 )\t3\t4\n", [[2, 3, 4]]), ("(1, 2)\t3\t4\t\n", [[2, 3, 4]]),
+                       ("(1, -2)\t3\t4\n", [[-2, 3, 4]])]:
+        f = tmp_path / "odd.test.negative"
+        f.write_text(text)
+        assert D.read_test_negative(f)[1].tolist() == want, text
+    for text in ["(1, 2)\t3x\t4\n", "(1, 2)\t3.0\t4\n", "(1, 2)\t3\t4\n(1 2)\t3\t4\n", "(1, 2)\t3\t4\n(1, 2)\t3\n"]:
+        f = tmp_path / "bad.test.negative"
+        f.write_text(text)
+        assert D._read_test_negative_fast(text) is None, text
+        with pytest.raises(ValueError):
+            D.read_test_negative(f)
