@@ -703,6 +703,122 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_kernel(Pair
     }
 }
 
+// Quarter-staged form of the pair-list kernel (tables under 2^23 rows, GMF width <= 32).  The layer-1 activations are staged one K QUARTER at a time.
+// LOOK = 2: the rows travel in two register sets of one quarter each (64 VGPRs in flight instead of 128): quarter c is stored
+// from set c & 1 right before quad 4 c is read, and the set is refilled with quarter c + 2 (of this group or the next).
+// LOOK = 1: one register set (32 VGPRs in flight), refilled with quarter c + 1 -- few enough registers for three waves per SIMD.
+template <int G, bool L3, int WAVES, bool BIG, bool CLAMP, int LOOK>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_q_kernel(PairArgs a)
+{
+    constexpr int GS = G + 4;
+    constexpr int WAVE_FLOATS = 32 * QSP + (G > 0 ? 32 * GS : 0);
+    constexpr int NG = G > 0 ? (32 * (G / 4)) / 64 : 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_img = smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    float* s_x = smem + LDS_IMG_SIZE<L3> + wave * WAVE_FLOATS;   // [32][QSP]  one K quarter of this wave's layer-1 activations
+    float* s_gp = s_x + 32 * QSP;                                // [32][GS]   gmf products
+
+    load_image_scaled<L3, 64 * WAVES>(s_img, a.img, tid, CLAMP ? layer1_scale(a.l1) : Layer1Scale{1.f, 1.f});
+    __syncthreads();
+
+    const int64_t ngroups = (a.B + 31) / 32;
+    const int64_t stride = (int64_t)gridDim.x * WAVES;
+    int64_t grp = (int64_t)blockIdx.x * WAVES + wave;
+    f32x4 p0[4], q0[4], p1[LOOK == 2 ? 4 : 1], q1[LOOK == 2 ? 4 : 1];   // register sets 0 / 1
+    f32x4 gu[NG], gi[NG];
+    int nu = 0, ni = 0;
+    int64_t ru = 0, ri = 0;                               // raw ids of the group after next (lanes 0..31)
+    if (grp < ngroups) {
+        pair_ids(a, grp * 32, lane, nu, ni);
+        pair_load_quarter<BIG>(a, nu, ni, lane, 0, p0, q0);
+        if constexpr (LOOK == 2) pair_load_quarter<BIG>(a, nu, ni, lane, 1, p1, q1);
+        if constexpr (G > 0) pair_load_gmf<G, BIG>(a, nu, ni, lane, gu, gi);
+        if (grp + stride < ngroups) pair_ids_raw(a, (grp + stride) * 32, lane, ru, ri);
+    }
+    for (; grp < ngroups; grp += stride) {
+        const int64_t base = grp * 32;
+        const bool more = grp + stride < ngroups;
+        pair_store_quarter<CLAMP>(s_x, lane, p0, q0);                      // quarter 0
+        if constexpr (G > 0) pair_store_gmf<G>(s_gp, lane, gu, gi);
+        __builtin_amdgcn_wave_barrier();
+        pair_load_quarter<BIG>(a, nu, ni, lane, LOOK, p0, q0);             // quarter 2 (1) of THIS group
+        int nu2 = 0, ni2 = 0;
+        if (more) {
+            pair_ids_clamp(a, (grp + stride) * 32, lane, ru, ri, nu2, ni2);     // loaded one group ago
+            if constexpr (G > 0) pair_load_gmf<G, BIG>(a, nu2, ni2, lane, gu, gi);
+            if (grp + 2 * stride < ngroups) pair_ids_raw(a, (grp + 2 * stride) * 32, lane, ru, ri);
+        }
+        const float* xrow = s_x + j * QSP + 4 * h;
+        struct X1Quarter {
+            const PairArgs& a;
+            const float* xrow;
+            float* s_x;
+            f32x4* p0; f32x4* q0; f32x4* p1; f32x4* q1;
+            int nu, ni, nu2, ni2;
+            int lane;
+            bool more;
+            __device__ __forceinline__ void pre(int q) const
+            {
+                if constexpr (LOOK == 2) {
+                    if (q == 4) {                 // quads 0..3 have all been read: quarter 1 in, quarter 3 on its way
+                        pair_store_quarter<CLAMP>(s_x, lane, p1, q1);
+                        __builtin_amdgcn_wave_barrier();
+                        pair_load_quarter<BIG>(a, nu, ni, lane, 3, p1, q1);
+                    } else if (q == 8) {          // quarter 2 in, the NEXT group's quarter 0 on its way
+                        pair_store_quarter<CLAMP>(s_x, lane, p0, q0);
+                        __builtin_amdgcn_wave_barrier();
+                        if (more) pair_load_quarter<BIG>(a, nu2, ni2, lane, 0, p0, q0);
+                    } else if (q == 12) {         // quarter 3 in, the next group's quarter 1 on its way
+                        pair_store_quarter<CLAMP>(s_x, lane, p1, q1);
+                        __builtin_amdgcn_wave_barrier();
+                        if (more) pair_load_quarter<BIG>(a, nu2, ni2, lane, 1, p1, q1);
+                    }
+                } else {
+                    if (q == 4 || q == 8) {       // quarter q / 4 in, the following one on its way
+                        pair_store_quarter<CLAMP>(s_x, lane, p0, q0);
+                        __builtin_amdgcn_wave_barrier();
+                        pair_load_quarter<BIG>(a, nu, ni, lane, q / 4 + 1, p0, q0);
+                    } else if (q == 12) {         // quarter 3 in, the NEXT group's quarter 0 on its way
+                        pair_store_quarter<CLAMP>(s_x, lane, p0, q0);
+                        __builtin_amdgcn_wave_barrier();
+                        if (more) pair_load_quarter<BIG>(a, nu2, ni2, lane, 0, p0, q0);
+                    }
+                }
+            }
+            __device__ __forceinline__ f32x4 raw(int q) const { return *reinterpret_cast<const f32x4*>(xrow + 8 * (q & 3)); }
+            __device__ __forceinline__ f32x4 finish(int, f32x4 v) const { return v; }
+            __device__ __forceinline__ f32x4 passthrough(f32x4 v) const { return v; }
+            __device__ __forceinline__ float between() const { return 0.f; }
+        };
+        float part = tower_mlp_part<L3>(s_img, lane, X1Quarter{a, xrow, s_x, p0, q0, p1, q1, nu, ni, nu2, ni2, lane, more});
+        if constexpr (G > 0) {
+            const float* grow = s_gp + j * GS + h * (G / 2);
+            const float* wpg = s_img + lds_img<L3>(IMG_WPG) + h * (G / 2);
+            float gm = 0.f;
+#pragma unroll
+            for (int c = 0; c < G / 8; ++c) {
+                const f32x4 gp = *reinterpret_cast<const f32x4*>(grow + 4 * c);
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wpg + 4 * c);
+                gm = fmaf(gp.x, w.x, gm);
+                gm = fmaf(gp.y, w.y, gm);
+                gm = fmaf(gp.z, w.z, gm);
+                gm = fmaf(gp.w, w.w, gm);
+            }
+            part = gm + part;
+        }
+        const float total = part + __shfl_xor(part, 32) + a.bp;
+        const int64_t b = base + j;
+        if (h == 0 && b < a.B) a.out[b] = epilogue(total, a.act, a.lo, a.hi);
+        __builtin_amdgcn_wave_barrier();
+        nu = nu2; ni = ni2;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // GMF-only model (model_name == 'GMF', ncf_model.py:232-234): score = w . (eu * ei) + b
 // ---------------------------------------------------------------------------------------------
@@ -898,16 +1014,37 @@ int launch_pairs_tb(const PairArgs& a, hipStream_t s)
 {
     // 8 waves per workgroup when their half-row staging areas fit next to the image (G <= 32: 148 KB), else 4 (six waves of the
     // Hybrid shape fit since its LDS image dropped layer 3, but measured slower: 1M pair rows 1.11 -> 1.19 ms)
-    constexpr int WAVES = G <= 32 ? 8 : 4;
-    constexpr size_t lds = (size_t)(LDS_IMG_SIZE<L3> + WAVES * (32 * HS + (G > 0 ? 32 * (G + 4) : 0))) * sizeof(float);
-    static_assert(lds <= 160 * 1024, "pair kernel LDS budget");
-    static bool attr[RECO_MAX_DEVICES] = {};
-    if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&tower_pairs_kernel<G, L3, WAVES, BIG, CLAMP>), lds, attr)) return rc;
-    const int64_t nchunks = ceil_div64(a.B, 32 * WAVES);
-    const unsigned grid = (unsigned)(nchunks < 256 ? nchunks : 256);   // persistent: one workgroup per CU
-    hipLaunchKernelGGL((tower_pairs_kernel<G, L3, WAVES, BIG, CLAMP>), dim3(grid), dim3(64 * WAVES), lds, s, a);
-    RECO_CHECK_LAUNCH();
-    return RECO_OK;
+    if constexpr (G <= 32 && !BIG) {
+        // Quarter-staged form, one quarter in flight: 168 VGPRs, so twelve waves (three per SIMD) share the image (152.5 KB).
+        // Same-box A/B against the half-staged kernel below (RECO_HIP_LIB variants, 11.5 M protocol pairs / random users):
+        //   half rows, 8 waves (256 VGPRs)        1.90 / 1.98 ms
+        //   quarters, two in flight, 8 waves      1.88 / 1.96 ms   (194 VGPRs)
+        //   quarters, one in flight, 8 waves      1.87 / 1.96 ms
+        //   quarters, one in flight, 12 waves     1.79 / 1.90 ms   <- this
+        // Tables of 2^23 rows or more (64-bit row offsets, rows from HBM rather than L2) and the Hybrid shape (its 64-wide GMF
+        // rows fill the LDS at 8 waves; measured level) stay on the half-staged kernel with its longer look-ahead.
+        constexpr int WAVES = 12, LOOK = 1;
+        constexpr size_t lds = (size_t)(LDS_IMG_SIZE<L3> + WAVES * (32 * QSP + (G > 0 ? 32 * (G + 4) : 0))) * sizeof(float);
+        static_assert(lds <= 160 * 1024, "pair kernel LDS budget");
+        static bool attr[RECO_MAX_DEVICES] = {};
+        if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&tower_pairs_q_kernel<G, L3, WAVES, BIG, CLAMP, LOOK>), lds, attr)) return rc;
+        const int64_t nchunks = ceil_div64(a.B, 32 * WAVES);
+        const unsigned grid = (unsigned)(nchunks < 256 ? nchunks : 256);   // persistent: one workgroup per CU
+        hipLaunchKernelGGL((tower_pairs_q_kernel<G, L3, WAVES, BIG, CLAMP, LOOK>), dim3(grid), dim3(64 * WAVES), lds, s, a);
+        RECO_CHECK_LAUNCH();
+        return RECO_OK;
+    } else {
+        constexpr int WAVES = G <= 32 ? 8 : 4;
+        constexpr size_t lds = (size_t)(LDS_IMG_SIZE<L3> + WAVES * (32 * HS + (G > 0 ? 32 * (G + 4) : 0))) * sizeof(float);
+        static_assert(lds <= 160 * 1024, "pair kernel LDS budget");
+        static bool attr[RECO_MAX_DEVICES] = {};
+        if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&tower_pairs_kernel<G, L3, WAVES, BIG, CLAMP>), lds, attr)) return rc;
+        const int64_t nchunks = ceil_div64(a.B, 32 * WAVES);
+        const unsigned grid = (unsigned)(nchunks < 256 ? nchunks : 256);   // persistent: one workgroup per CU
+        hipLaunchKernelGGL((tower_pairs_kernel<G, L3, WAVES, BIG, CLAMP>), dim3(grid), dim3(64 * WAVES), lds, s, a);
+        RECO_CHECK_LAUNCH();
+        return RECO_OK;
+    }
 }
 
 template <int G, bool L3>

@@ -403,6 +403,33 @@ __device__ __forceinline__ void pair_store_half(float* s_x, int lane, const f32x
         *reinterpret_cast<f32x4*>(s_x + (4 * it + r) * HS + 4 * c) = CLAMP ? add_clamp4(p[it], q[it]) : relu4(p[it] + q[it]);
 }
 
+// ---- quarter-row staging (tower_pairs_q_kernel) --------------------------------------------------------------
+// One K quarter (32 of 128 features) of P and Q per register set: a wave instruction reads 8 rows x 128 contiguous bytes,
+// register group `it` (0..3) holds float4 column c = lane & 7 of rows 8 it + (lane >> 3).  Staged as [32 pairs][QSP] per wave.
+constexpr int QSP = 32 + 4;
+
+template <bool BIG>
+__device__ __forceinline__ void pair_load_quarter(const PairArgs& a, int my_u, int my_i, int lane, int quarter, f32x4* p, f32x4* q)
+{
+    const int c = lane & 7, r = lane >> 3;
+    const float* Pq = a.P + 32 * quarter;          // the quarter is part of the uniform base (see pair_load_half)
+    const float* Qq = a.Q + 32 * quarter;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        p[it] = *row_chunk<BIG>(Pq, __shfl(my_u, 8 * it + r), H1, c);
+        q[it] = *row_chunk<BIG>(Qq, __shfl(my_i, 8 * it + r), H1, c);
+    }
+}
+
+template <bool CLAMP>
+__device__ __forceinline__ void pair_store_quarter(float* s_x, int lane, const f32x4* p, const f32x4* q)
+{
+    const int c = lane & 7, r = lane >> 3;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+        *reinterpret_cast<f32x4*>(s_x + (8 * it + r) * QSP + 4 * c) = CLAMP ? add_clamp4(p[it], q[it]) : relu4(p[it] + q[it]);
+}
+
 template <int G, bool BIG>
 __device__ __forceinline__ void pair_load_gmf(const PairArgs& a, int my_u, int my_i, int lane, f32x4* gu, f32x4* gi)
 {
