@@ -206,7 +206,10 @@ __device__ __forceinline__ float split_mlp_part(const bf16x8* s_w, const float* 
     for (int s = 0; s < 7; ++s) {
         const W6 wn = load_w2(s_w, s + 1, lane);
         X8 qn = q;
-        if (s + 2 < 8) qn = x1.raw(s + 2);
+        if (s + 2 < 8) {
+            x1.stage(s + 2);                 // (quarter-staged pair kernel: k-steps 2c, 2c + 1 are staged right before raw(2c))
+            qn = x1.raw(s + 2);
+        }
         FENCE();
         auto pre = [&](int pr, int wh) { return x1.pre(s + 1, q, 2 * pr + wh); };
 #pragma unroll
@@ -354,6 +357,7 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tower_tile_split_kernel(TileA
                         return X8{*reinterpret_cast<const f32x4*>(qrow + 16 * s), *reinterpret_cast<const f32x4*>(qrow + 16 * s + 4)};
                     }
                     enum { RELU = 1 };
+                    __device__ __forceinline__ void stage(int) const {}
                     __device__ __forceinline__ float pre(int s, const X8& q, int e) const
                     {
                         return (e < 4 ? p[2 * s][e] : p[2 * s + 1][e - 4]) + x8_get(q, e);
@@ -431,6 +435,7 @@ __global__ __launch_bounds__(256, 1) void tower_pairs_split_kernel(PairArgs a)
                 return X8{*reinterpret_cast<const f32x4*>(xrow + 16 * s), *reinterpret_cast<const f32x4*>(xrow + 16 * s + 4)};
             }
             enum { RELU = 0 };                          // the staged tile holds relu(P + Q)
+            __device__ __forceinline__ void stage(int) const {}
             __device__ __forceinline__ float pre(int, const X8& q, int e) const { return x8_get(q, e); }
         };
         float part = split_mlp_part<L3>(s_w, s_tail, lane, X1Pair{xrow});
@@ -451,6 +456,120 @@ __global__ __launch_bounds__(256, 1) void tower_pairs_split_kernel(PairArgs a)
         const int64_t b = base + j;
         if (h == 0 && b < a.B) a.out[b] = epilogue(total, a.act, a.lo, a.hi);
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Quarter-staged form (tables under 2^23 rows), as tower_pairs_q_kernel in tower.hip: relu(P + Q) is staged one K quarter (two
+// k-steps of 16 features) at a time, LOOK register sets of one quarter each carry the rows.  The whole-row kernel above holds
+// 128 VGPRs of rows and runs ONE wave per SIMD; this one runs two.
+template <int G, bool L3, int WAVES, int LOOK>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_split_q_kernel(PairArgs a)
+{
+    constexpr int GS = G + 4;
+    constexpr int WAVE_FLOATS = 32 * QSP + (G > 0 ? 32 * GS : 0);
+    constexpr int NG = G > 0 ? (32 * (G / 4)) / 64 : 1;
+    constexpr int WU = spl_w_units(L3);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const bf16x8* s_w = reinterpret_cast<const bf16x8*>(smem);
+    const float* s_tail = smem + WU * 4;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    float* s_x = smem + WU * 4 + SPL_TAIL + wave * WAVE_FLOATS;
+    float* s_gp = s_x + 32 * QSP;
+
+    for (int i = tid; i < spl_bytes(L3) / 16; i += 64 * WAVES)
+        reinterpret_cast<f32x4*>(smem)[i] = reinterpret_cast<const f32x4*>(a.img)[i];
+    __syncthreads();
+
+    const int64_t ngroups = (a.B + 31) / 32;
+    const int64_t stride = (int64_t)gridDim.x * WAVES;
+    int64_t grp = (int64_t)blockIdx.x * WAVES + wave;
+    f32x4 p0[4], q0[4], p1[LOOK == 2 ? 4 : 1], q1[LOOK == 2 ? 4 : 1];
+    f32x4 gu[NG], gi[NG];
+    int nu = 0, ni = 0;
+    int64_t ru = 0, ri = 0;
+    if (grp < ngroups) {
+        pair_ids(a, grp * 32, lane, nu, ni);
+        pair_load_quarter<false>(a, nu, ni, lane, 0, p0, q0);
+        if constexpr (LOOK == 2) pair_load_quarter<false>(a, nu, ni, lane, 1, p1, q1);
+        if constexpr (G > 0) pair_load_gmf<G, false>(a, nu, ni, lane, gu, gi);
+        if (grp + stride < ngroups) pair_ids_raw(a, (grp + stride) * 32, lane, ru, ri);
+    }
+    for (; grp < ngroups; grp += stride) {
+        const int64_t base = grp * 32;
+        const bool more = grp + stride < ngroups;
+        pair_store_quarter<false>(s_x, lane, p0, q0);                      // quarter 0
+        if constexpr (G > 0) pair_store_gmf<G>(s_gp, lane, gu, gi);
+        __builtin_amdgcn_wave_barrier();
+        pair_load_quarter<false>(a, nu, ni, lane, LOOK, p0, q0);
+        int nu2 = 0, ni2 = 0;
+        if (more) {
+            pair_ids_clamp(a, (grp + stride) * 32, lane, ru, ri, nu2, ni2);
+            if constexpr (G > 0) pair_load_gmf<G, false>(a, nu2, ni2, lane, gu, gi);
+            if (grp + 2 * stride < ngroups) pair_ids_raw(a, (grp + 2 * stride) * 32, lane, ru, ri);
+        }
+        const float* xrow = s_x + j * QSP + 8 * h;
+        struct X1Quarter {
+            const PairArgs& a;
+            const float* xrow;
+            float* s_x;
+            f32x4* p0; f32x4* q0; f32x4* p1; f32x4* q1;
+            int nu, ni, nu2, ni2;
+            int lane;
+            bool more;
+            __device__ __forceinline__ void stage(int s) const       // before raw(s); s = 2, 4, 6 open quarters 1, 2, 3
+            {
+                if (s & 1) return;
+                if constexpr (LOOK == 2) {
+                    if (s == 2) {
+                        pair_store_quarter<false>(s_x, lane, p1, q1);
+                        __builtin_amdgcn_wave_barrier();
+                        pair_load_quarter<false>(a, nu, ni, lane, 3, p1, q1);
+                    } else if (s == 4) {
+                        pair_store_quarter<false>(s_x, lane, p0, q0);
+                        __builtin_amdgcn_wave_barrier();
+                        if (more) pair_load_quarter<false>(a, nu2, ni2, lane, 0, p0, q0);
+                    } else if (s == 6) {
+                        pair_store_quarter<false>(s_x, lane, p1, q1);
+                        __builtin_amdgcn_wave_barrier();
+                        if (more) pair_load_quarter<false>(a, nu2, ni2, lane, 1, p1, q1);
+                    }
+                } else {
+                    pair_store_quarter<false>(s_x, lane, p0, q0);
+                    __builtin_amdgcn_wave_barrier();
+                    if (s < 6) pair_load_quarter<false>(a, nu, ni, lane, s / 2 + 1, p0, q0);
+                    else if (more) pair_load_quarter<false>(a, nu2, ni2, lane, 0, p0, q0);
+                }
+            }
+            __device__ __forceinline__ X8 raw(int s) const
+            {
+                return X8{*reinterpret_cast<const f32x4*>(xrow + 16 * (s & 1)), *reinterpret_cast<const f32x4*>(xrow + 16 * (s & 1) + 4)};
+            }
+            enum { RELU = 0 };                          // the staged quarter holds relu(P + Q)
+            __device__ __forceinline__ float pre(int, const X8& q, int e) const { return x8_get(q, e); }
+        };
+        float part = split_mlp_part<L3>(s_w, s_tail, lane, X1Quarter{a, xrow, s_x, p0, q0, p1, q1, nu, ni, nu2, ni2, lane, more});
+        if constexpr (G > 0) {
+            const float* grow = s_gp + j * GS + h * (G / 2);
+            const float* wpg = s_tail + TAIL_WPG + h * (G / 2);
+#pragma unroll
+            for (int c = 0; c < G / 8; ++c) {
+                const f32x4 gp = *reinterpret_cast<const f32x4*>(grow + 4 * c);
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wpg + 4 * c);
+                part = fmaf(gp.x, w.x, part);
+                part = fmaf(gp.y, w.y, part);
+                part = fmaf(gp.z, w.z, part);
+                part = fmaf(gp.w, w.w, part);
+            }
+        }
+        const float total = part + __shfl_xor(part, 32) + a.bp;
+        const int64_t b = base + j;
+        if (h == 0 && b < a.B) a.out[b] = epilogue(total, a.act, a.lo, a.hi);
+        __builtin_amdgcn_wave_barrier();
+        nu = nu2; ni = ni2;
     }
 }
 
@@ -478,6 +597,23 @@ int launch_tile_split_t(const TileArgs& a, hipStream_t s)
 template <int G, bool L3>
 int launch_pairs_split_t(const PairArgs& a, hipStream_t s)
 {
+    // Quarter-staged form for tables under 2^23 rows and GMF width <= 32 (same-box A/B, 11.5 M protocol pairs: whole rows, one
+    // wave per SIMD 1.666 ms; quarters, two in flight, two waves per SIMD 1.28 ms; one in flight 1.26 ms <- this).  The Hybrid
+    // shape needs 256 VGPRs + spill in this form and keeps the whole-row kernel.
+    if constexpr (G <= 32) {
+        if (a.n_users < (1ll << 23) && a.n_items < (1ll << 23)) {
+            constexpr int WAVES = 8, LOOK = 1;
+            constexpr size_t ldsq = (size_t)spl_bytes(L3) + (size_t)(WAVES * (32 * QSP + (G > 0 ? 32 * (G + 4) : 0))) * sizeof(float);
+            static_assert(ldsq <= 160 * 1024, "split pair kernel LDS budget");
+            static bool attrq[RECO_MAX_DEVICES] = {};
+            if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&tower_pairs_split_q_kernel<G, L3, WAVES, LOOK>), ldsq, attrq)) return rc;
+            const int64_t nch = ceil_div64(a.B, 32 * WAVES);
+            const unsigned gridq = (unsigned)(nch < 256 ? nch : 256);
+            hipLaunchKernelGGL((tower_pairs_split_q_kernel<G, L3, WAVES, LOOK>), dim3(gridq), dim3(64 * WAVES), ldsq, s, a);
+            RECO_CHECK_LAUNCH();
+            return RECO_OK;
+        }
+    }
     constexpr size_t lds = (size_t)spl_bytes(L3) + (size_t)(4 * (32 * QS + (G > 0 ? 32 * (G + 4) : 0))) * sizeof(float);
     static_assert(lds <= 160 * 1024, "split pair kernel LDS budget");
     static bool attr[RECO_MAX_DEVICES] = {};

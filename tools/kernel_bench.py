@@ -139,11 +139,11 @@ def bench_tower():
     u = torch.randint(0, 6038, (115056,), generator=g).repeat_interleave(100).to(dev)
     i = torch.randint(0, 3533, (B,), generator=g).to(dev)
     ms = timeit(lambda: t.score_pairs(u, i, check_ids=False))
-    emit("tower_pairs_kernel<32,true>", "B=%d (115,056 cases x 100)" % B, ms, "mfma", B * NEUMF_EXEC, "20,768 FLOP/pair executed (86,176 algorithmic)",
+    emit("tower_pairs_q_kernel<32,true>", "B=%d (115,056 cases x 100)" % B, ms, "mfma", B * NEUMF_EXEC, "20,768 FLOP/pair executed (86,176 algorithmic)",
          "pairs/s = %.3g" % (B / ms * 1e3), B * NEUMF_ALG)
     ur = torch.randint(0, 6038, (B,), generator=g).to(dev)
     ms = timeit(lambda: t.score_pairs(ur, i, check_ids=False))
-    emit("tower_pairs_kernel<32,true>", "B=%d random users" % B, ms, "mfma", B * NEUMF_EXEC, "20,768 FLOP/pair executed", "pairs/s = %.3g" % (B / ms * 1e3), B * NEUMF_ALG)
+    emit("tower_pairs_q_kernel<32,true>", "B=%d random users" % B, ms, "mfma", B * NEUMF_EXEC, "20,768 FLOP/pair executed", "pairs/s = %.3g" % (B / ms * 1e3), B * NEUMF_ALG)
     out = torch.empty(6038, 3533, device=dev)
     ms = timeit(lambda: t.score_matrix(None, None, check_ids=False, out=out))
     emit("tower_tile_kernel<32,true> (+projections)", "6038 x 3533", ms, "mfma", 6038 * 3533 * NEUMF_EXEC, "20,768 FLOP/pair executed",
@@ -151,7 +151,7 @@ def bench_tower():
     ops.set_tower_precision("bf16x3")
     ts = m._tower(dev)
     ms = timeit(lambda: ts.score_pairs(u, i, check_ids=False))
-    emit("tower_pairs_split_kernel<32,true> (bf16x3)", "B=%d (115,056 cases x 100)" % B, ms, "mfma", B * NEUMF_EXEC,
+    emit("tower_pairs_split_q_kernel<32,true> (bf16x3)", "B=%d (115,056 cases x 100)" % B, ms, "mfma", B * NEUMF_EXEC,
          "20,768 fp32-equivalent FLOP/pair executed, against the FP32 MFMA peak", "pairs/s = %.3g" % (B / ms * 1e3), B * NEUMF_ALG)
     ms = timeit(lambda: ts.score_matrix(None, None, check_ids=False, out=out))
     emit("tower_tile_split_kernel<32,true> (bf16x3, +projections)", "6038 x 3533", ms, "mfma", 6038 * 3533 * NEUMF_EXEC,
