@@ -9,7 +9,7 @@ for r in 1 2; do
 import sys,json,os,re
 for l in sys.stdin:
     d=json.loads(l)
-    if re.search(os.environ.get('AB_FILTER','pairs_kernel'), d['kernel']): print(os.environ['V'], d['kernel'][:48], d['shape'][:24], round(d['ms'],4))
+    if re.search(os.environ.get('AB_FILTER','pairs'), d['kernel']): print(os.environ['V'], d['kernel'][:48], d['shape'][:24], round(d['ms'],4))
 "
   done
 done
