@@ -703,7 +703,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_kernel(Pair
     }
 }
 
-// Quarter-staged form of the pair-list kernel (tables under 2^23 rows, GMF width <= 32).  The layer-1 activations are staged one K QUARTER at a time.
+// Quarter-staged form of the pair-list kernel (GMF width <= 32).  The layer-1 activations are staged one K QUARTER at a time.
 // LOOK = 2: the rows travel in two register sets of one quarter each (64 VGPRs in flight instead of 128): quarter c is stored
 // from set c & 1 right before quad 4 c is read, and the set is refilled with quarter c + 2 (of this group or the next).
 // LOOK = 1: one register set (32 VGPRs in flight), refilled with quarter c + 1 -- few enough registers for three waves per SIMD.
@@ -1014,16 +1014,18 @@ int launch_pairs_tb(const PairArgs& a, hipStream_t s)
 {
     // 8 waves per workgroup when their half-row staging areas fit next to the image (G <= 32: 148 KB), else 4 (six waves of the
     // Hybrid shape fit since its LDS image dropped layer 3, but measured slower: 1M pair rows 1.11 -> 1.19 ms)
-    if constexpr (G <= 32 && !BIG) {
+    if constexpr (G <= 32) {
         // Quarter-staged form, one quarter in flight: 168 VGPRs, so twelve waves (three per SIMD) share the image (152.5 KB).
         // Same-box A/B against the half-staged kernel below (RECO_HIP_LIB variants, 11.5 M protocol pairs / random users):
         //   half rows, 8 waves (256 VGPRs)        1.90 / 1.98 ms
         //   quarters, two in flight, 8 waves      1.88 / 1.96 ms   (194 VGPRs)
         //   quarters, one in flight, 8 waves      1.87 / 1.96 ms
         //   quarters, one in flight, 12 waves     1.79 / 1.90 ms   <- this
-        // Tables of 2^23 rows or more (64-bit row offsets, rows from HBM rather than L2) and the Hybrid shape (its 64-wide GMF
-        // rows fill the LDS at 8 waves; measured level) stay on the half-staged kernel with its longer look-ahead.
-        constexpr int WAVES = 12, LOOK = 1;
+        // Tables of 2^23 rows or more (64-bit row offsets: 12 waves would spill 60 VGPRs) run it with 8 waves: 9 M users x 100 k
+        // items, 11.5 M pairs from HBM-resident tables (tools/big_pairs_bench.py): half rows 2.56 / 2.16 ms (random users / runs of
+        // 100 per user), quarters two in flight 2.38 / 1.99, one in flight 2.34 / 1.93 <- this, 12 waves 2.80 / 2.21.
+        // The Hybrid shape (its 64-wide GMF rows fill the LDS at 8 waves; measured level) stays on the half-staged kernel.
+        constexpr int WAVES = BIG ? 8 : 12, LOOK = 1;
         constexpr size_t lds = (size_t)(LDS_IMG_SIZE<L3> + WAVES * (32 * QSP + (G > 0 ? 32 * (G + 4) : 0))) * sizeof(float);
         static_assert(lds <= 160 * 1024, "pair kernel LDS budget");
         static bool attr[RECO_MAX_DEVICES] = {};
