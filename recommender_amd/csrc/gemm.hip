@@ -106,14 +106,27 @@ __device__ __forceinline__ f32x4 load_k4(const float* row, int64_t k, int64_t K)
 // K is consumed in BK = 32 tiles through a double-buffered LDS image: the global loads of tile t+1 are issued before
 // the MFMAs of tile t and written to the other buffer after them -- one barrier per tile, no branch in the steady state
 // (rows past M / N are clamped to the last row and discarded at the store; only the ragged last K tile is guarded).
-template <int BM, int BN, int VEC, bool AT, bool SPLIT, bool ONE>
-__global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
+// DMAT: 16-byte aligned rows of the exact form are staged with global_load_lds_dwordx4 -- straight into LDS, no staging registers
+// (32 VGPRs: the single-buffered form then fits 128 and four workgroups share a CU instead of three), no ds_write, and in the
+// double-buffered form the next tile is in flight under the MFMAs without occupying a register.  A lane's 16 bytes land at the
+// wave's LDS window + 16 lane (tools/lds_dma_probe.hip), so rows cannot be padded; instead the 16-byte chunks of a row are
+// XOR-swizzled with bits 1..3 of the row number: the lane that owns LDS position p of row R fetches global chunk
+// p ^ ((R >> 1) & 7), and a fragment read of chunk c goes to position c ^ ((R >> 1) & 7) -- 16 rows x b128 then hit 16 distinct
+// 4-bank slots, as with the padded layout.  The ragged last K tile still goes through registers (zero fill), into the same layout.
+// Same-box A/B (tools/gemm_variant_ab.sh): AutoRec decoder 0.243 -> 0.234 ms, split-K encoder 0.237 -> 0.232, 4096^3 1.12 -> 1.095;
+// single-buffered launches with fewer than 12 K tiles lose (a workgroup has nothing in flight while it waits: the Hybrid
+// encoders' K = 256 / 128 layers +1.5 %) and keep the register path.
+template <int BM, int BN, int VEC, bool AT, bool SPLIT, bool ONE, bool DMAT>
+__global__ __launch_bounds__(256, DMAT ? (ONE ? 4 : 2) : 1) void linear_kernel(LinArgs a)
 {
+    static_assert(!DMAT || (!AT && !SPLIT && VEC == 4), "LDS-direct staging: plain exact form with 16-byte aligned rows only");
+    constexpr bool DMA = DMAT;
+    constexpr int LSD = DMA ? BK : LS;          // LDS row stride of the exact form
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int RA = BM / 32, RB = BN / 32;   // float4 per thread per operand per K tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // layout: [buf][A tile BM*LS | B tile BN*LS] floats;  split form: [buf][piece(3)][A tile BM*LSB | B tile BN*LSB] bf16
-    constexpr int BUF = SPLIT ? 3 * (BM + BN) * LSB / 2 : (BM + BN) * LS;      // in floats
+    constexpr int BUF = SPLIT ? 3 * (BM + BN) * LSB / 2 : (BM + BN) * LSD;     // in floats
     constexpr int PIECE = (BM + BN) * LSB;                                      // bf16 per piece image
     // split form and transposed A: ONE LDS image, so more workgroups share a CU and one's staging (global loads, operand
     // splitting / transposing, LDS writes) overlaps the others' MFMAs (measured: transposed encoder 0.30 -> 0.26 ms, split
@@ -140,7 +153,9 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
     const int64_t ke = kb + a.k_per_split < a.K ? kb + a.k_per_split : a.K;
 
     // staging assignment: thread -> (row r = tid/8 + 32*s, float4 column c = tid%8)
-    const int sr = tid >> 3, sc = tid & 7;
+    const int sr = tid >> 3, sc_pos = tid & 7;
+    const int sc = DMA ? (sc_pos ^ ((sr >> 1) & 7)) : sc_pos;      // the GLOBAL chunk this thread fetches (DMA: swizzled)
+    const int sw_f = DMA ? ((i >> 1) & 7) : 0;                     // swizzle key of this lane's fragment rows
     const float* arow[RA];
     const float* wrow[RB];
 #pragma unroll
@@ -265,7 +280,7 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
             return;
         }
         float* s_a = smem + buf * BUF;
-        float* s_b = s_a + BM * LS;
+        float* s_b = s_a + BM * LSD;
         if constexpr (AT) {   // [m][k] image from k-major registers: row 4 tc + i gets element i of each of the RA loads
 #pragma unroll
             for (int i4 = 0; i4 < 4; ++i4) {
@@ -279,21 +294,44 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
             }
         } else {
 #pragma unroll
-            for (int s = 0; s < RA; ++s) *reinterpret_cast<f32x4*>(s_a + (sr + 32 * s) * LS + 4 * sc) = ra[s];
+            for (int s = 0; s < RA; ++s) *reinterpret_cast<f32x4*>(s_a + (sr + 32 * s) * LSD + 4 * sc_pos) = ra[s];
         }
 #pragma unroll
-        for (int s = 0; s < RB; ++s) *reinterpret_cast<f32x4*>(s_b + (sr + 32 * s) * LS + 4 * sc) = rb[s];
+        for (int s = 0; s < RB; ++s) *reinterpret_cast<f32x4*>(s_b + (sr + 32 * s) * LSD + 4 * sc_pos) = rb[s];
+    };
+    // DMA: tile t into the LDS image; a full tile goes straight from global memory, the ragged last one through registers
+    auto stage_dma = [&](int64_t t, int buf, bool wait) {
+        if (ragged && t == nt - 1) {
+            load_tile(t);
+            store_tile(buf);
+        } else {
+            const int64_t k0 = t * BK;
+            typedef const __attribute__((address_space(1))) void* gptr_t;
+            typedef __attribute__((address_space(3))) void* lptr_t;
+#pragma unroll
+            for (int s = 0; s < RA; ++s)
+                __builtin_amdgcn_global_load_lds((gptr_t)(arow[s] + k0), (lptr_t)(smem + buf * BUF + (32 * s + 8 * wave) * BK), 16, 0, 0);
+#pragma unroll
+            for (int s = 0; s < RB; ++s)
+                __builtin_amdgcn_global_load_lds((gptr_t)(wrow[s] + k0), (lptr_t)(smem + buf * BUF + BM * BK + (32 * s + 8 * wave) * BK), 16, 0, 0);
+        }
+        if (wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
-    load_tile(0);
-    store_tile(0);
+    if constexpr (DMA) {
+        stage_dma(0, 0, true);
+    } else {
+        load_tile(0);
+        store_tile(0);
+    }
     __syncthreads();
 
     for (int64_t t = 0; t < nt; ++t) {
 #ifdef RECO_ABL_GEMM_NO_LOAD       // timing-only ablation: every K tile re-stages the first one's registers
         if (t + 1 < nt && a.K < 0) load_tile(t + 1);
 #else
-        if (t + 1 < nt) load_tile(t + 1);
+        if constexpr (!DMA) { if (t + 1 < nt) load_tile(t + 1); }
+        else if constexpr (NBUF == 2) { if (t + 1 < nt) stage_dma(t + 1, (int)((t + 1) & 1), false); }   // in flight under the MFMAs
 #endif
         if constexpr (SPLIT) {
             const unsigned short* pa = reinterpret_cast<const unsigned short*>(smem + (t & (NBUF - 1)) * BUF) + (wm * (BM / 2) + i) * LSB + 8 * h;
@@ -319,15 +357,16 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
                             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][ta[term]], fb[tn][tb[term]], acc[tm][tn], 0, 0, 0);
             }
         } else {
-        const float* s_a = smem + (t & (NBUF - 1)) * BUF + (wm * (BM / 2) + i) * LS + 4 * h;
-        const float* s_b = smem + (t & (NBUF - 1)) * BUF + BM * LS + (wn * (BN / 2) + i) * LS + 4 * h;
+        const float* s_a = smem + (t & (NBUF - 1)) * BUF + (wm * (BM / 2) + i) * LSD + (DMA ? 0 : 4 * h);
+        const float* s_b = smem + (t & (NBUF - 1)) * BUF + BM * LSD + (wn * (BN / 2) + i) * LSD + (DMA ? 0 : 4 * h);
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {
             f32x4 fa[TM], fb[TN];
+            const int fo = DMA ? 4 * ((2 * q + h) ^ sw_f) : 8 * q;      // chunk 2 q + h of the row (DMA: at its swizzled position)
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) fa[tm] = *reinterpret_cast<const f32x4*>(s_a + tm * 32 * LS + 8 * q);
+            for (int tm = 0; tm < TM; ++tm) fa[tm] = *reinterpret_cast<const f32x4*>(s_a + tm * 32 * LSD + fo);
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) fb[tn] = *reinterpret_cast<const f32x4*>(s_b + tn * 32 * LS + 8 * q);
+            for (int tn = 0; tn < TN; ++tn) fb[tn] = *reinterpret_cast<const f32x4*>(s_b + tn * 32 * LSD + fo);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
@@ -337,7 +376,12 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a)
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm][jj], fb[tn][jj], acc[tm][tn], 0, 0, 0);
         }
         }
-        if constexpr (NBUF == 1) {
+        if constexpr (DMA && NBUF == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if constexpr (DMA) {
+            __syncthreads();                       // every wave is done reading the image
+            if (t + 1 < nt) stage_dma(t + 1, 0, true);
+        } else if constexpr (NBUF == 1) {
             __syncthreads();                       // every wave is done reading the image
             if (t + 1 < nt) store_tile(0);
         } else {
@@ -382,15 +426,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(LinArgs a)
     }
 }
 
-template <int BM, int BN, int VEC, bool AT, bool SPLIT, bool ONE>
+template <int BM, int BN, int VEC, bool AT, bool SPLIT, bool ONE, bool DMAT = false>
 int launch_k(const LinArgs& a, hipStream_t s)
 {
     constexpr size_t lds = SPLIT ? (size_t)3 * (BM + BN) * LSB * 2 : (size_t)((AT || ONE) ? 1 : 2) * (BM + BN) * LS * sizeof(float);
     static bool attr[RECO_MAX_DEVICES] = {};
-    if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&linear_kernel<BM, BN, VEC, AT, SPLIT, ONE>), lds, attr)) return rc;
+    if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&linear_kernel<BM, BN, VEC, AT, SPLIT, ONE, DMAT>), lds, attr)) return rc;
     const int64_t blocks = ceil_div64(a.M, BM) * ceil_div64(a.N, BN) * a.splits;
     RECO_REQUIRE(blocks < (1ll << 31), "linear grid too large");
-    hipLaunchKernelGGL((linear_kernel<BM, BN, VEC, AT, SPLIT, ONE>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((linear_kernel<BM, BN, VEC, AT, SPLIT, ONE, DMAT>), dim3((unsigned)blocks), dim3(256), lds, s, a);
     RECO_CHECK_LAUNCH();
     return RECO_OK;
 }
@@ -399,8 +443,13 @@ template <int BM, int BN, int VEC, bool AT, bool SPLIT>
 int launch_v(const LinArgs& a, hipStream_t s)
 {
     int rc;
-    if constexpr (!AT && !SPLIT) rc = a.k_per_split <= 768 ? launch_k<BM, BN, VEC, AT, SPLIT, true>(a, s) : launch_k<BM, BN, VEC, AT, SPLIT, false>(a, s);
-    else rc = launch_k<BM, BN, VEC, AT, SPLIT, false>(a, s);
+    if constexpr (!AT && !SPLIT && VEC == 4) {              // 16-byte aligned rows: LDS-direct staging (see linear_kernel)
+        if (a.k_per_split > 768) rc = launch_k<BM, BN, VEC, AT, SPLIT, false, true>(a, s);
+        else if (a.k_per_split >= 12 * BK) rc = launch_k<BM, BN, VEC, AT, SPLIT, true, true>(a, s);
+        else rc = launch_k<BM, BN, VEC, AT, SPLIT, true, false>(a, s);
+    } else if constexpr (!AT && !SPLIT) {
+        rc = a.k_per_split <= 768 ? launch_k<BM, BN, VEC, AT, SPLIT, true>(a, s) : launch_k<BM, BN, VEC, AT, SPLIT, false>(a, s);
+    } else rc = launch_k<BM, BN, VEC, AT, SPLIT, false>(a, s);
     if (rc) return rc;
     if (a.splits > 1) {
         const int64_t rb = ceil_div64(a.M * a.N, 256);
