@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, DMAT ? (ONE ? 4 : 2) : 1) void linear_kernel(L
     // splitting / transposing, LDS writes) overlaps the others' MFMAs (measured: transposed encoder 0.30 -> 0.26 ms, split
     // 4096^3 0.93 -> 0.76 ms); the plain exact form double-buffers inside the workgroup (4096^3: 1.09 vs 1.21 ms single)
     // ONE: the plain exact form with a short K (<= 768 per slice, e.g. the AutoRec decoder's 500): a tile is then mostly
-    // prologue and epilogue, and four single-buffered workgroups per CU overlap those better than two double-buffered ones
+    // prologue and epilogue, and three (with LDS-direct staging: four) single-buffered workgroups per CU overlap those better than two double-buffered ones
     // (decoder 0.250 -> 0.243 ms, the Hybrid encoders' six launches 0.357 -> 0.308 ms; 864-wide slices of the AutoRec encoder's
     // split K were 1.6 % slower this way, and at K = 4096 the double buffer wins 1.09 vs 1.21 ms)
     constexpr int NBUF = (SPLIT || AT || ONE) ? 1 : 2;
