@@ -376,7 +376,10 @@ def test_linear_shapes_and_epilogues(tower_precision):
     from recommender_amd import ops
     rng = np.random.default_rng(6)
     for M, N, K in ((1, 1, 1), (7, 5, 3), (130, 70, 33), (300, 500, 6040 // 8), (257, 129, 100), (64, 64, 32), (100, 6, 3706 // 2 + 1),
-                    (300, 70, 2500), (128, 256, 4099)):      # the last two take the split-K path
+                    (300, 70, 2500), (128, 256, 4099),       # these two take the split-K path
+                    # 16-byte aligned rows: LDS-direct staging (gemm.hip DMAT) -- single-buffered from 12 K tiles on, with a
+                    # whole and with a ragged last tile, at its 384 threshold, and double-buffered beyond 768
+                    (200, 300, 512), (130, 70, 500), (100, 100, 384), (100, 100, 388), (70, 200, 380), (129, 257, 1024), (260, 130, 1028)):
         x = rng.standard_normal((M, K)).astype(np.float32); w = rng.standard_normal((N, K)).astype(np.float32)
         b = rng.standard_normal(N).astype(np.float32)
         ref = x.astype(np.float64) @ w.astype(np.float64).T + b
