@@ -58,6 +58,12 @@ def parse_args(argv=None):
                          "because RCCL refuses two ranks on one device); checks the N > 1 code path on a 1-GPU box, the numbers "
                          "mean nothing")
     ap.add_argument("--launch-timeout", type=float, default=600.0, help="seconds before the self-started ranks are taken to be hung")
+    ap.add_argument("--precondition", type=int, default=48,
+                    help="untimed steps BEFORE the W warm-up steps of each cfg2 region: the device clock needs ~30 ms of load after "
+                         "idle to settle (profiles/r03_torchrun_gap.md), which W = 3..5 steps of 3 ms do not give it")
+    ap.add_argument("--no-kernels", action="store_true",
+                    help="skip the per-kernel sections (fields gather, cfg1_protocol, cfg3_autorec, cfg4_hybrid; N = 1 only)")
+    ap.add_argument("--kernel-steps", type=int, default=10)
     return ap.parse_args(argv)
 
 
@@ -76,19 +82,62 @@ def launcher_argv(argv, gpus, port):
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
-def _run_children(cmd, env, timeout_s):
-    """Runs cmd in its own process group; returns (exit code or None on timeout, stdout text)."""
+def _descendants(pid):
+    """Every live descendant of pid, by walking /proc (torch elastic starts its workers in sessions of their own, so they are
+    NOT in the agent's process group and a killpg on the agent does not reach them)."""
+    parent = {}
+    for d in os.listdir("/proc"):
+        if d.isdigit():
+            try:
+                with open("/proc/%s/stat" % d) as f:
+                    parent[int(d)] = int(f.read().rsplit(")", 1)[1].split()[1])
+            except (OSError, ValueError, IndexError):
+                pass
+    out, frontier = [], [pid]
+    while frontier:
+        frontier = [c for c, pp in parent.items() if pp in frontier]
+        out += frontier
+    return out
+
+
+def _alive(pid):
+    try:
+        with open("/proc/%d/stat" % pid) as f:
+            return f.read().rsplit(")", 1)[1].split()[0] != "Z"
+    except OSError:
+        return False
+
+
+def _run_children(cmd, env, timeout_s, grace_s=10.0):
+    """Runs cmd in its own process group; returns (exit code or None on timeout, stdout text, pids that survived the clean-up).
+
+    On timeout the agent gets SIGTERM first (its handler ends the workers it started), then, after a grace period, SIGKILL goes
+    to the agent's group and to every descendant recorded BEFORE the first signal."""
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
     try:
         out, _ = proc.communicate(timeout=timeout_s)
-        return proc.returncode, out.decode(errors="replace")
+        return proc.returncode, out.decode(errors="replace"), []
     except subprocess.TimeoutExpired:
+        kids = _descendants(proc.pid)
+        try:
+            proc.send_signal(signal.SIGTERM)
+            proc.wait(grace_s)
+        except (subprocess.TimeoutExpired, ProcessLookupError):
+            pass
         try:
             os.killpg(proc.pid, signal.SIGKILL)          # exactly the group started above
         except ProcessLookupError:
             pass
+        for pid in kids:
+            try:
+                os.kill(pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
         out, _ = proc.communicate()
-        return None, out.decode(errors="replace")
+        deadline = time.time() + 5.0
+        while time.time() < deadline and any(_alive(p) for p in kids):
+            time.sleep(0.1)
+        return None, out.decode(errors="replace"), [p for p in kids if _alive(p)]
 
 
 def _result_line(text):
@@ -103,12 +152,36 @@ def _result_line(text):
     return None
 
 
+def visible_gpus():
+    """GPUs this process may use, WITHOUT opening the HIP runtime: the *_VISIBLE_DEVICES lists, else the KFD topology (nodes with
+    SIMDs are GPUs); torch.cuda.device_count() only when neither says anything (it calls hipGetDeviceCount when amdsmi is absent)."""
+    counts = []
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            counts.append(len([x for x in v.split(",") if x.strip() != ""]))
+    if counts:
+        return min(counts)
+    nodes = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for d in os.listdir(nodes):
+            with open(os.path.join(nodes, d, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+        if n:
+            return n
+    except (OSError, ValueError):
+        pass
+    return torch.cuda.device_count()
+
+
 def self_launch(args, argv):
     """Parent of a plain `bench.py --gpus N`: never initialises the GPU, starts the ranks, relays rank 0's JSON line.
 
     A run whose ranks fail or hang with the overlapped gather is repeated once, in fresh processes, with one blocking
     all-gather per step (RECO_BENCH_SYNC_GATHER=1): a hang cannot be recovered from inside the hung process."""
-    visible = torch.cuda.device_count()                   # counting devices does not initialise the GPU
+    visible = visible_gpus()
     if visible < args.gpus and not args.share_gpus:
         raise SystemExit("bench.py: --gpus %d but only %d GPU(s) are visible (use --share-gpus to rehearse the N-rank path on "
                          "fewer devices)" % (args.gpus, visible))
@@ -123,8 +196,12 @@ def self_launch(args, argv):
         attempts.append(("blocking", {"RECO_BENCH_SYNC_GATHER": "1", "RECO_BENCH_FELL_BACK": "1"}))
     for mode, extra in attempts:
         cmd = launcher_argv(argv, args.gpus, free_port())
-        rc, out = _run_children(cmd, dict(env, **extra), args.launch_timeout)
+        rc, out, survivors = _run_children(cmd, dict(env, **extra), args.launch_timeout)
         line = _result_line(out)
+        if survivors:      # ranks that outlived SIGKILL still hold the GPUs: a second attempt next to them would measure nothing
+            print("bench.py: rank processes %s survived the clean-up of the %s-gather attempt; not starting another" % (survivors, mode),
+                  file=sys.stderr, flush=True)
+            return 1
         if rc == 0 and line:
             sys.stdout.write(line + "\n")
             sys.stdout.flush()
@@ -220,6 +297,24 @@ def mfma_roofline(kernel, pairs_per_launch, kernel_ms, launches, traffic=None, t
     return r
 
 
+def parallelism_text(world, share_gpus, pipelined, reserve):
+    """What the ranks actually do with the top-k lists, in words (config.parallelism)."""
+    if world == 1:
+        return "one rank: all users on this GPU, no collective is issued (user-sharded with replicated tables at N > 1)"
+    backend = "gloo (REHEARSAL: ranks share GPUs, numbers meaningless)" if share_gpus else "RCCL"
+    if not pipelined:
+        how = ("one blocking all-gather per step; the pipelined form failed and the ranks were restarted" if os.environ.get("RECO_BENCH_FELL_BACK") == "1"
+               else "one blocking all-gather per step (RECO_BENCH_SYNC_GATHER=1)")
+    elif reserve:
+        how = ("pipelined: the gather of step i is enqueued behind step i's top-k and awaited before step i + 2; the tile kernels leave "
+               "%d of the CUs free (RECO_RESERVE_CUS) so that the gather kernel can run under step i + 1's tile launch" % reserve)
+    else:
+        how = ("pipelined: the gather of step i is enqueued behind step i's top-k and awaited before step i + 2; the persistent tile "
+               "kernel fills every CU's LDS, so the gather kernel runs in the gap between two tile launches (beside the projection / "
+               "select kernels), not under one; RECO_RESERVE_CUS=r would keep r CUs free for it")
+    return "user-sharded x%d, replicated tables, %s all-gather of packed top-k (%s)" % (world, backend, how)
+
+
 def main_rank(args):
     # stdout carries exactly ONE line, the result: everything else that writes to file descriptor 1 in this process (RCCL prints
     # a version banner there at communicator creation) goes to stderr instead
@@ -277,16 +372,25 @@ def main_rank(args):
             return done
 
     pipelined = os.environ.get("RECO_BENCH_SYNC_GATHER", "0") != "1"
+    from recommender_amd.dist import reserved_cus_setting
+    reserve = reserved_cus_setting() if world > 1 else 0
+
+    spread = {}                                   # per-launch spread of the tile kernel's duration, by precision
 
     def timed_run(precision):
         """W warm-up steps, then K timed steps between fences; (seconds max over ranks, mean ms of the tile kernel, ids, vals)."""
         ops.set_tower_precision(precision)
-        # step i's all-gather overlaps step i + 1's kernels
+        # step i's all-gather is enqueued behind step i's kernels and not waited for before step i + 2 (N > 1; one rank gathers nothing)
         pipe = TopkGather(model, K, total_users) if pipelined else _SyncGather()
-        for _ in range(args.warmup):
+        fence()                                  # first barrier of the process group (communicator set-up) outside everything timed
+        # The device clock needs ~30 ms of load to settle after idle (a tile launch runs 3.6 ms cold, 3.13 ms settled), and any
+        # host-side pause -- a process group's first barrier -- sends it back: `--precondition` untimed steps (the SAME fixed
+        # count on every rank) come before the W warm-up steps, so that the K timed steps see the sustained clock.
+        for _ in range(max(args.precondition, 0) + args.warmup):
             pipe.step()
         pipe.flush()
-        _lib.check(L.reco_profile_enable(args.steps + 4))
+        cap = args.steps + 4                     # the tile kernel's launches only: an event pair costs ~4 us of stream time
+        _lib.check(L.reco_profile_enable_kinds(cap, 1 << _lib.PROF_TOWER))
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -294,11 +398,15 @@ def main_rank(args):
         ids, vals = pipe.flush()
         fence()
         el = time.perf_counter() - t0
-        ms = (ctypes.c_float * (args.steps + 4))()
+        ms = (ctypes.c_float * cap)()
         n = ctypes.c_int(0)
-        _lib.check(L.reco_profile_collect(ms, args.steps + 4, ctypes.byref(n)))
+        _lib.check(L.reco_profile_collect(ms, cap, ctypes.byref(n)))
         _lib.check(L.reco_profile_enable(0))
-        kernel_ms = float(np.mean(list(ms)[: n.value])) if n.value else float("nan")
+        per_launch = np.asarray(list(ms)[: n.value], np.float64)
+        kernel_ms = float(per_launch.mean()) if n.value else float("nan")
+        spread[precision] = {"median": float(np.median(per_launch)), "min": float(per_launch.min()), "max": float(per_launch.max())} if n.value else None
+        if os.environ.get("RECO_BENCH_DEBUG") == "1":
+            print("tile kernel ms per launch (%s): %s" % (precision, " ".join("%.3f" % x for x in list(ms)[: n.value])), file=sys.stderr, flush=True)
         t = torch.tensor([el], dtype=torch.float64, device=device)
         if launched:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -324,6 +432,12 @@ def main_rank(args):
             if rank == 0:
                 cfg5["split_bf16x3"] = {k: s5[k] for k in ("value", "unit", "pairs_per_s", "ms_per_step", "roofline")}
 
+    kernels = None
+    if world == 1 and not args.no_kernels:       # the other roofline targets of north_star (one GPU is their whole story: SURVEY 8e)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_kernels
+        kernels = bench_kernels.run(model, device, args.kernel_steps, 3)
+
     if rank == 0:
         pairs_per_rank = N_USERS * N_ITEMS
         pairs = pairs_per_rank * world * args.steps
@@ -338,14 +452,13 @@ def main_rank(args):
                                    "6038 users x 3533 items = 21,332,254 pairs per GPU per step (`value`); cfg5 (10M x 1M, top-100) in "
                                    "`cfg5_top100`, same ranks, same protocol",
                        "users_per_gpu": N_USERS, "items": N_ITEMS, "k": K, "weights": "random init, reference ctor order, seed 0, embeddings x25",
-                       "parallelism": "user-sharded x%d, replicated tables, %s all-gather of top-k (%s)" % (
-                           world, "gloo (REHEARSAL: ranks share GPUs, numbers meaningless)" if args.share_gpus else "RCCL",
-                           "overlapped with the next step's kernels" if pipelined else
-                           ("blocking; the overlapped form failed and the ranks were restarted" if os.environ.get("RECO_BENCH_FELL_BACK") == "1"
-                            else "blocking (RECO_BENCH_SYNC_GATHER=1)"))},
+                       "precondition_steps": max(args.precondition, 0),
+                       "parallelism": parallelism_text(world, args.share_gpus, pipelined, reserve)},
             "roofline": mfma_roofline("tower_tile_kernel<32,true>", pairs_per_rank, tile_ms, n_timed, traffic, traffic_src,
                                       algorithmic_bytes=pairs_per_rank * 4),
         }
+        if spread.get("f32"):
+            res["roofline"]["kernel_ms_per_launch"] = spread["f32"]
         if split is not None:
             s_elapsed, s_tile_ms, _, s_ids, s_vals = split
             dev = (s_vals - vals).abs() / vals.abs().clamp_min(1e-30)
@@ -358,6 +471,8 @@ def main_rank(args):
                         "terms on v_mfma_f32_32x32x16_bf16, fp32 accumulate; passes the same parity tests as the exact mode"}
         if cfg5 is not None:
             res["cfg5_top100"] = cfg5
+        if kernels is not None:
+            res.update(kernels)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(model, ids.cpu().numpy(), vals.cpu().numpy())
         os.write(result_fd, (json.dumps(res) + "\n").encode())

@@ -32,7 +32,10 @@
  *     pre-activation exceeds 2^80, gets a finite, meaningless score where the reference has inf / NaN / a huge value; every
  *     other pair is unaffected by such rows;
  *   - nothing allocates except *_create (the packed-model handles) -- scratch memory is
- *     brought in by the caller as `ws` / `ws_bytes` (query the size with *_workspace_bytes).
+ *     brought in by the caller as `ws` / `ws_bytes` (query the size with *_workspace_bytes);
+ *   - mutable state outside the handles: the thread-local error string, the thread-local measurement hook
+ *     (reco_profile_*, armed per host thread), and the per-device address of the static scratch array of
+ *     reco_tower_score_topk_noalloc (looked up once under a lock).  Nothing else is shared between threads.
  */
 #ifndef RECO_HIP_H
 #define RECO_HIP_H
@@ -187,6 +190,14 @@ typedef struct reco_tower_desc {
 int  reco_tower_create(const reco_tower_desc_t* desc, void* stream, reco_tower_t** out);
 void reco_tower_destroy(reco_tower_t* t);
 
+/* Multi-GPU helper, NO COUNTERPART IN THE REFERENCE (which is single-device).  The persistent tile kernels of score_matrix /
+ * score_topk launch one workgroup per CU and each takes 152 of the CU's 160 KB of LDS, so a kernel of another stream -- RCCL's
+ * all-gather of the previous step's top-k lists (recommender_amd/dist.py) -- finds no CU until a tile launch ends.  With
+ * cus > 0 the tile kernels of this handle launch (CUs - cus) workgroups; tiles come from a work queue, so results do not change.
+ * 0 (the default) = every CU.  cus in [0, 128].  Applies to calls issued after it returns; not synchronised with calls that
+ * run concurrently on other host threads. */
+int reco_tower_set_reserved_cus(reco_tower_t* t, int cus);
+
 /* forward(user, item) -> score[B]           src/helpers/ncf_model.py:188-249
  * Out-of-range ids never fault: they are clamped and counted in *oob (see Conventions). */
 int reco_tower_score_pairs(reco_tower_t* t, const int64_t* user, const int64_t* item, int64_t B,
@@ -294,15 +305,36 @@ int reco_topk_rows_seen(const float* scores, int64_t src_rows, int64_t N, int64_
                         int32_t* out_ids, float* out_vals, int32_t* oob, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Measurement hook (no counterpart in the reference): when enabled, the library brackets every
- * launch of the dominant kernel (the tower tile kernel of score_matrix / score_topk, or the pair
- * kernel of score_pairs / score_rows) with a hipEvent pair recorded on the launch stream.
- * reco_profile_enable(n) allocates n event pairs (n = 0 disables and frees them);
- * reco_profile_collect synchronises the recorded events and returns per-launch milliseconds
- * (host pointers), then rearms.  Used by bench.py for roofline.achieved.
+ * Measurement hook (no counterpart in the reference): when armed, the library brackets the launch of each
+ * roofline kernel with a hipEvent pair recorded on the launch stream, so that a caller can time the KERNEL
+ * (not the call) without a profiler.  The hook belongs to the calling HOST THREAD: reco_profile_enable(n)
+ * allocates n event pairs for the calling thread (n = 0 disarms and frees them) and only launches issued by
+ * that thread are bracketed; other threads are unaffected and nothing is shared between threads.
+ * What is bracketed (kind):
+ *   RECO_PROF_TOWER   tower tile / tile+top-k / pair kernel of reco_tower_score_*
+ *   RECO_PROF_GATHER  reco_gather_rows, reco_neumf_gather
+ *   RECO_PROF_LINEAR  the GEMM kernel of reco_linear_f32 / reco_autorec_forward (and of the tower's layer-1 projections);
+ *                     a split-K reduce launch is RECO_PROF_LINEAR_REDUCE
+ *   RECO_PROF_CSR     the segment kernel of reco_csr_linear_f32 (its reduce launch: RECO_PROF_CSR_REDUCE)
+ *   RECO_PROF_TOPK    the scan / lane kernel of reco_topk_rows* (its merge launch: RECO_PROF_TOPK_MERGE)
+ *   RECO_PROF_ENCODER the fused layer-2/3 kernel of reco_mlp2_f32
+ * reco_profile_collect_kinds synchronises the recorded events and returns per-launch milliseconds and kinds in launch order
+ * (host pointers; kind_out nullable), then rearms.  reco_profile_collect returns the RECO_PROF_TOWER launches only.
  * ---------------------------------------------------------------------------------------- */
-int reco_profile_enable(int max_launches);
+#define RECO_PROF_TOWER          1
+#define RECO_PROF_GATHER         2
+#define RECO_PROF_LINEAR         3
+#define RECO_PROF_LINEAR_REDUCE  4
+#define RECO_PROF_CSR            5
+#define RECO_PROF_CSR_REDUCE     6
+#define RECO_PROF_TOPK           7
+#define RECO_PROF_TOPK_MERGE     8
+#define RECO_PROF_ENCODER        9
+int reco_profile_enable(int max_launches);                                    /* every kind */
+int reco_profile_enable_kinds(int max_launches, unsigned kind_mask);          /* only kinds k with bit (1u << k) set: an event pair
+                                                                                 costs a few microseconds of stream time */
 int reco_profile_collect(float* ms_out /*host*/, int capacity, int* n_out /*host*/);
+int reco_profile_collect_kinds(float* ms_out /*host*/, int32_t* kind_out /*host, nullable*/, int capacity, int* n_out /*host*/);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,8 @@ LIB_PATH = os.environ.get("RECO_HIP_LIB") or os.path.join(_HERE, "lib", "libreco
 OK, EINVAL, EHIP, ENOMEM, EINDEX = 0, -1, -2, -3, -4
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_CLAMP, ACT_RATING = 0, 1, 2, 3, 4
 PREC_F32, PREC_SPLIT_BF16X3 = 0, 1
-ABI_VERSION = 4
+PROF_TOWER, PROF_GATHER, PROF_LINEAR, PROF_LINEAR_REDUCE, PROF_CSR, PROF_CSR_REDUCE, PROF_TOPK, PROF_TOPK_MERGE, PROF_ENCODER = range(1, 10)
+ABI_VERSION = 5
 
 
 class TowerDesc(Structure):
@@ -50,6 +51,7 @@ _SIGNATURES = {
                                      c_int, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "reco_tower_create": (c_int, [POINTER(TowerDesc), c_void_p, POINTER(c_void_p)]),
     "reco_tower_destroy": (None, [c_void_p]),
+    "reco_tower_set_reserved_cus": (c_int, [c_void_p, c_int]),
     "reco_tower_score_pairs": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "reco_tower_rows_workspace_bytes": (c_size_t, [c_int64]),
     "reco_tower_score_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
@@ -76,7 +78,9 @@ _SIGNATURES = {
     "reco_topk_rows_seen": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int64,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "reco_profile_enable": (c_int, [c_int]),
+    "reco_profile_enable_kinds": (c_int, [c_int, ctypes.c_uint]),
     "reco_profile_collect": (c_int, [POINTER(c_float), c_int, POINTER(c_int)]),
+    "reco_profile_collect_kinds": (c_int, [POINTER(c_float), POINTER(c_int32), c_int, POINTER(c_int)]),
 }
 
 EXPORTS = tuple(sorted(_SIGNATURES))

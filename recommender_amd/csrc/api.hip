@@ -15,7 +15,7 @@ int tower_launch_tile(int G, int has_l3, const float* img, const float* P, const
                       const float* EUg, const float* EIg, const int64_t* users, const int64_t* cands,
                       int64_t user_base, int64_t n_users, int64_t n_items, int64_t U, int64_t N,
                       float* out, int64_t ld_out, float bp, int act, float lo, float hi, int32_t* oob,
-                      unsigned int* next_tile, const float* l1, hipStream_t s);
+                      unsigned int* next_tile, const float* l1, int reserve_cus, hipStream_t s);
 int tower_launch_l1scale(const float* W1, const float* b1, int dm, const float* u_rows, int64_t u_elems,
                          const float* i_rows, int64_t i_elems, unsigned int* scratch, float* out, hipStream_t s);
 int tower_launch_pairs(int G, int has_l3, const float* img, const float* P, const float* Q,
@@ -29,7 +29,7 @@ int tower_launch_tile_split(int G, int has_l3, const void* img, const float* P, 
                             const float* EUg, const float* EIg, const int64_t* users, const int64_t* cands,
                             int64_t user_base, int64_t n_users, int64_t n_items, int64_t U, int64_t N,
                             float* out, int64_t ld_out, float bp, int act, float lo, float hi, int32_t* oob,
-                            unsigned int* next_tile, hipStream_t s);
+                            unsigned int* next_tile, int reserve_cus, hipStream_t s);
 int tower_launch_pairs_split(int G, int has_l3, const void* img, const float* P, const float* Q,
                              const float* EUg, const float* EIg, const int64_t* user, const int64_t* item,
                              int64_t n_users, int64_t n_items, int64_t B, float* out, float bp, int act,
@@ -41,7 +41,7 @@ int tower_launch_tile_topk(int G, int has_l3, const float* img, const float* P, 
                            int64_t user_base, int64_t n_users, int64_t n_items, int64_t U, int64_t N,
                            float bp, int act, float lo, float hi, int32_t* oob,
                            int k, int v_max, unsigned int* counters, unsigned long long* partial,
-                           const float* l1, hipStream_t s);
+                           const float* l1, int reserve_cus, hipStream_t s);
 int gmf_launch_pairs(const float* EUg, const float* EIg, const float* wp, const int64_t* user,
                      const int64_t* item, int64_t n_users, int64_t n_items, int64_t B, int G, float* out,
                      float bp, int act, float lo, float hi, int32_t* oob, hipStream_t s);
@@ -64,63 +64,91 @@ void reco_set_error(const char* fmt, ...)
 }
 
 extern "C" const char* reco_last_error(void) { return g_err; }
-extern "C" int reco_abi_version(void) { return 4; }
+extern "C" int reco_abi_version(void) { return 5; }
 
 // ---------------------------------------------------------------------------------------------
-// measurement hook: hipEvent pairs around the dominant kernel's launches
+// measurement hook: hipEvent pairs around kernel launches, armed per host thread (no state shared between threads)
 // ---------------------------------------------------------------------------------------------
 #include <mutex>
 #include <vector>
-static std::mutex g_prof_mu;                 // the hook is process-wide; scoring calls may come from several threads
-static std::vector<hipEvent_t> g_prof_ev;   // 2 per launch
-static int g_prof_used = 0;
+namespace {
+struct ProfState {
+    std::vector<hipEvent_t> ev;   // 2 per launch
+    std::vector<int> kind;        // per launch
+    int used = 0;
+    unsigned mask = ~0u;          // kinds that are bracketed (bit k = RECO_PROF_* value k)
+};
+thread_local ProfState t_prof;
+}  // namespace
 
-extern "C" int reco_profile_enable(int max_launches)
+extern "C" int reco_profile_enable_kinds(int max_launches, unsigned kind_mask);
+extern "C" int reco_profile_enable(int max_launches) { return reco_profile_enable_kinds(max_launches, ~0u); }
+
+extern "C" int reco_profile_enable_kinds(int max_launches, unsigned kind_mask)
 {
-    std::lock_guard<std::mutex> lock(g_prof_mu);
-    for (hipEvent_t e : g_prof_ev) (void)hipEventDestroy(e);
-    g_prof_ev.clear();
-    g_prof_used = 0;
+    ProfState& p = t_prof;
+    p.mask = kind_mask;
+    for (hipEvent_t e : p.ev) (void)hipEventDestroy(e);
+    p.ev.clear();
+    p.kind.clear();
+    p.used = 0;
     for (int i = 0; i < 2 * max_launches; ++i) {
         hipEvent_t e;
         RECO_CHECK_HIP(hipEventCreate(&e));
-        g_prof_ev.push_back(e);
+        p.ev.push_back(e);
     }
+    p.kind.assign(max_launches > 0 ? max_launches : 0, 0);
     return RECO_OK;
 }
 
+extern "C" int reco_profile_collect_kinds(float* ms_out, int32_t* kind_out, int capacity, int* n_out)
+{
+    RECO_REQUIRE(ms_out && n_out, "profile_collect: null pointer");
+    ProfState& p = t_prof;
+    int n = 0;
+    for (int i = 0; i < p.used && n < capacity; ++i, ++n) {
+        RECO_CHECK_HIP(hipEventSynchronize(p.ev[2 * i + 1]));
+        RECO_CHECK_HIP(hipEventElapsedTime(&ms_out[n], p.ev[2 * i], p.ev[2 * i + 1]));
+        if (kind_out) kind_out[n] = p.kind[i];
+    }
+    *n_out = n;
+    p.used = 0;
+    return RECO_OK;
+}
+
+// the tower kernels' launches only (the form bench.py's headline region has used since round 1)
 extern "C" int reco_profile_collect(float* ms_out, int capacity, int* n_out)
 {
     RECO_REQUIRE(ms_out && n_out, "profile_collect: null pointer");
-    std::lock_guard<std::mutex> lock(g_prof_mu);
+    ProfState& p = t_prof;
     int n = 0;
-    for (int i = 0; i < g_prof_used && n < capacity; ++i, ++n) {
-        RECO_CHECK_HIP(hipEventSynchronize(g_prof_ev[2 * i + 1]));
-        RECO_CHECK_HIP(hipEventElapsedTime(&ms_out[n], g_prof_ev[2 * i], g_prof_ev[2 * i + 1]));
+    for (int i = 0; i < p.used && n < capacity; ++i) {
+        if (p.kind[i] != RECO_PROF_TOWER) continue;
+        RECO_CHECK_HIP(hipEventSynchronize(p.ev[2 * i + 1]));
+        RECO_CHECK_HIP(hipEventElapsedTime(&ms_out[n], p.ev[2 * i], p.ev[2 * i + 1]));
+        ++n;
     }
     *n_out = n;
-    g_prof_used = 0;
+    p.used = 0;
     return RECO_OK;
 }
 
-struct ProfScope {
-    hipStream_t s;
-    int slot;
-    explicit ProfScope(hipStream_t st) : s(st), slot(-1)
-    {
-        std::lock_guard<std::mutex> lock(g_prof_mu);
-        if ((size_t)(2 * g_prof_used + 1) < g_prof_ev.size()) {
-            slot = g_prof_used++;
-            (void)hipEventRecord(g_prof_ev[2 * slot], s);
-        }
+ProfScope::ProfScope(hipStream_t st, int kind) : s(st), slot(-1)
+{
+    ProfState& p = t_prof;
+    if ((size_t)(2 * p.used + 1) < p.ev.size() && ((p.mask >> kind) & 1u)) {
+        slot = p.used++;
+        p.kind[slot] = kind;
+        (void)hipEventRecord(p.ev[2 * slot], s);
     }
-    ~ProfScope()
-    {
-        if (slot < 0) return;
-        std::lock_guard<std::mutex> lock(g_prof_mu);
-        if ((size_t)(2 * slot + 1) < g_prof_ev.size()) (void)hipEventRecord(g_prof_ev[2 * slot + 1], s);
-    }
-};
+}
+
+ProfScope::~ProfScope()
+{
+    if (slot < 0) return;
+    ProfState& p = t_prof;
+    if ((size_t)(2 * slot + 1) < p.ev.size()) (void)hipEventRecord(p.ev[2 * slot + 1], s);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Linear / AutoRec
@@ -220,6 +248,7 @@ struct reco_tower {
     float* l1;        // device words {s, 1/s}: the power of two layer 1 is scaled by (tower_shared.h), fixed by the handle's tables;
                       // null in split mode and for handles without tables (then per call, resolve_l1)
     int device;
+    int reserve_cus;  // CUs the persistent tile kernels leave without a workgroup (reco_tower_set_reserved_cus); 0 = none
 };
 
 // Layer-1 scale words {s, 1/s} (tower_shared.h).  Inside a 256-byte block: floats at words kL1Word, kL1Word + 1, two scratch
@@ -358,6 +387,14 @@ extern "C" int reco_tower_create(const reco_tower_desc_t* d, void* stream, reco_
     return RECO_OK;
 }
 
+extern "C" int reco_tower_set_reserved_cus(reco_tower_t* t, int cus)
+{
+    RECO_REQUIRE(t, "set_reserved_cus: null handle");
+    RECO_REQUIRE(cus >= 0 && cus <= 128, "set_reserved_cus: %d is outside [0, 128]", cus);
+    t->reserve_cus = cus;
+    return RECO_OK;
+}
+
 extern "C" int reco_tower_score_pairs(reco_tower_t* t, const int64_t* user, const int64_t* item, int64_t B,
                                       float* out, int32_t* oob, void* stream)
 {
@@ -371,7 +408,7 @@ extern "C" int reco_tower_score_pairs(reco_tower_t* t, const int64_t* user, cons
     if (!t->mfma)
         return gmf_launch_pairs(d.user_gmf, d.item_gmf, d.w_predict, user, item, d.n_users, d.n_items, B, d.dg, out,
                                 t->bp, d.act, d.lo, d.hi, oob, s);
-    ProfScope prof(s);
+    ProfScope prof(s, RECO_PROF_TOWER);
     return run_pairs(t, t->P, t->Q, d.user_gmf, d.item_gmf, user, item, d.n_users, d.n_items, B, out, oob, t->l1, s);
 }
 
@@ -418,7 +455,7 @@ extern "C" int reco_tower_score_rows(reco_tower_t* t, const float* u_gmf, const 
     // 1M Hybrid rows 1.00 -> 1.18 ms), so the projections stay unscaled and the pair kernel takes its add + max form.
     int rc = tower_project(t, u_mlp, nullptr, 0, B, i_mlp, nullptr, 0, B, P, Q, nullptr, nullptr, s);
     if (rc) return rc;
-    ProfScope prof(s);
+    ProfScope prof(s, RECO_PROF_TOWER);
     return run_pairs(t, P, Q, u_gmf, i_gmf, nullptr, nullptr, B, B, B, out, nullptr, nullptr, s);
 }
 
@@ -443,13 +480,13 @@ static int score_matrix_impl(reco_tower* t, const int64_t* users, int64_t user_b
     int rc = tower_project(t, urows, users, d.n_users, U, d.item_mlp, cands, d.n_items, Qready ? 0 : N, P, Q, oob, l1, s);
     if (rc) return rc;
     if (queue) RECO_CHECK_HIP(hipMemsetAsync(queue, 0, sizeof(unsigned int), s));
-    ProfScope prof(s);
+    ProfScope prof(s, RECO_PROF_TOWER);
     if (t->img_split)
         return tower_launch_tile_split(t->G, t->has_l3, t->img_split, P, Qready ? Qready : Q, d.user_gmf, d.item_gmf, users,
                                        cands, user_base, d.n_users, d.n_items, U, N, out, ld_out, t->bp, d.act, d.lo, d.hi,
-                                       oob, queue, s);
+                                       oob, queue, t->reserve_cus, s);
     return tower_launch_tile(t->G, t->has_l3, t->img, P, Qready ? Qready : Q, d.user_gmf, d.item_gmf, users, cands,
-                             user_base, d.n_users, d.n_items, U, N, out, ld_out, t->bp, d.act, d.lo, d.hi, oob, queue, l1, s);
+                             user_base, d.n_users, d.n_items, U, N, out, ld_out, t->bp, d.act, d.lo, d.hi, oob, queue, l1, t->reserve_cus, s);
 }
 
 static int check_ranges(const reco_tower* t, const int64_t* users, int64_t user_base, int64_t U, const int64_t* cands,
@@ -613,9 +650,9 @@ static int score_topk_fused(reco_tower_t* t, const int64_t* users, int64_t user_
         if ((int64_t)v * n > list_room) v = (int)(list_room / n);
         RECO_CHECK_HIP(hipMemsetAsync(counters, 0, counter_bytes + fused_partial_bytes(n, v, k), s));
         {
-            ProfScope prof(s);
+            ProfScope prof(s, RECO_PROF_TOWER);
             rc = tower_launch_tile_topk(t->G, t->has_l3, t->img, P, Q, d.user_gmf, d.item_gmf, ul, cands, user_base + c0, d.n_users,
-                                        d.n_items, n, N, t->bp, d.act, d.lo, d.hi, oob, k, v, counters, partial, l1, s);
+                                        d.n_items, n, N, t->bp, d.act, d.lo, d.hi, oob, k, v, counters, partial, l1, t->reserve_cus, s);
         }
         if (rc) return rc;
         if ((rc = launch_topk_merge(partial, n, v, k, out_ids + c0 * k, out_scores + c0 * k, s))) return rc;

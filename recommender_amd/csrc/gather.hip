@@ -145,6 +145,7 @@ extern "C" int reco_gather_rows(const float* table, int64_t rows, int dim, const
     RECO_REQUIRE(rows > 0, "gather_rows: empty table");
     RECO_REQUIRE((uintptr_t)table % 16 == 0 && (uintptr_t)out % 16 == 0, "gather_rows: table and out must be 16-byte aligned");
     const int sh = log2_exact(dim / 4);
+    ProfScope prof((hipStream_t)stream, RECO_PROF_GATHER);
     if (sh >= 0)
         hipLaunchKernelGGL(gather_rows_kernel<true>, dim3(stream_grid(B * (dim / 4))), dim3(256), 0, (hipStream_t)stream,
                            table, rows, dim / 4, sh, idx, B, out, oob);
@@ -176,6 +177,7 @@ extern "C" int reco_neumf_gather(const float* Eu_g, const float* Ei_g, const flo
     FusedArgs a{Eu_g, Ei_g, Eu_m, Ei_m, n_users, n_items, dg / 4, dm / 4, user, item, B, gmf_prod, mlp_in, ld_gmf / 4, ld_mlp / 4, oob};
     const int64_t work = B * (mlp_in ? 2 * (dm / 4) : dg / 4);
     const int sh_m = mlp_in ? log2_exact(2 * (dm / 4)) : 0, sh_g = gmf_prod ? log2_exact(dg / 4) : 0;
+    ProfScope prof((hipStream_t)stream, RECO_PROF_GATHER);
     if (sh_m >= 0 && sh_g >= 0)
         hipLaunchKernelGGL(neumf_gather_kernel<true>, dim3(stream_grid(work)), dim3(256), 0, (hipStream_t)stream, a, sh_m, sh_g);
     else

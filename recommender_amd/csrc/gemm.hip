@@ -434,7 +434,10 @@ int launch_k(const LinArgs& a, hipStream_t s)
     if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&linear_kernel<BM, BN, VEC, AT, SPLIT, ONE, DMAT>), lds, attr)) return rc;
     const int64_t blocks = ceil_div64(a.M, BM) * ceil_div64(a.N, BN) * a.splits;
     RECO_REQUIRE(blocks < (1ll << 31), "linear grid too large");
-    hipLaunchKernelGGL((linear_kernel<BM, BN, VEC, AT, SPLIT, ONE, DMAT>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    {
+        ProfScope prof(s, RECO_PROF_LINEAR);
+        hipLaunchKernelGGL((linear_kernel<BM, BN, VEC, AT, SPLIT, ONE, DMAT>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    }
     RECO_CHECK_LAUNCH();
     return RECO_OK;
 }
@@ -453,7 +456,10 @@ int launch_v(const LinArgs& a, hipStream_t s)
     if (rc) return rc;
     if (a.splits > 1) {
         const int64_t rb = ceil_div64(a.M * a.N, 256);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(rb < 4096 ? rb : 4096)), dim3(256), 0, s, a);
+        {
+            ProfScope prof(s, RECO_PROF_LINEAR_REDUCE);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(rb < 4096 ? rb : 4096)), dim3(256), 0, s, a);
+        }
         RECO_CHECK_LAUNCH();
     }
     return RECO_OK;

@@ -29,6 +29,15 @@ void reco_set_error(const char* fmt, ...);
 
 #define RECO_CHECK_LAUNCH() RECO_CHECK_HIP(hipGetLastError())
 
+// Measurement hook (api.hip; reco_profile_* in reco_hip.h): a hipEvent pair recorded on the launch stream around ONE kernel
+// launch, when the calling thread armed the hook.  `kind` is one of RECO_PROF_*.  Costs a thread-local load when disarmed.
+struct ProfScope {
+    hipStream_t s;
+    int slot;
+    ProfScope(hipStream_t stream, int kind);
+    ~ProfScope();
+};
+
 // Raises a kernel's dynamic-LDS limit once per device (the attribute is per device; `done` is the caller's
 // function-local table, one per kernel instantiation).
 constexpr int RECO_MAX_DEVICES = 64;

@@ -256,6 +256,7 @@ int launch_csr_linear(const int64_t* row_ptr, const int32_t* col, const float* v
     const bool fast = N % 4 == 0 && ldwt % 4 == 0 && (uintptr_t)Wt % 16 == 0 && (!bias || (uintptr_t)bias % 16 == 0) &&
                       (single_segment_rows || (uintptr_t)ws % 16 == 0);
     if (grid > 0) {
+        ProfScope prof(s, RECO_PROF_CSR);
         if (fast && N > 256)
             hipLaunchKernelGGL(csr_linear_wave_kernel<8>, dim3((unsigned)grid, (unsigned)ceil_div64(N, 512)), dim3(256), 0, s, a);
         else if (fast)
@@ -265,6 +266,7 @@ int launch_csr_linear(const int64_t* row_ptr, const int32_t* col, const float* v
         RECO_CHECK_LAUNCH();
     }
     if (!single_segment_rows) {
+        ProfScope prof(s, RECO_PROF_CSR_REDUCE);
         hipLaunchKernelGGL(csr_reduce_kernel, dim3((unsigned)M, (unsigned)ceil_div64(N, 256)), dim3(256), 0, s, a);
         RECO_CHECK_LAUNCH();
     }

@@ -396,6 +396,7 @@ int launch_topk_rows_ex(const float* scores, int64_t rows, int64_t N, int64_t ld
         const int64_t lblocks = ceil_div64(rows, 256);
         RECO_REQUIRE(lblocks < (1ll << 31), "topk grid too large");
         const bool v4 = ld % 4 == 0 && (uintptr_t)scores % 16 == 0;
+        ProfScope prof(s, RECO_PROF_TOPK);
         if (k <= 10) {
             if (v4) hipLaunchKernelGGL((topk_lane_kernel<10, 4>), dim3((unsigned)lblocks), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((topk_lane_kernel<10, 1>), dim3((unsigned)lblocks), dim3(256), 0, s, a);
@@ -428,17 +429,21 @@ int launch_topk_rows_ex(const float* scores, int64_t rows, int64_t N, int64_t ld
         if (masked) hipLaunchKernelGGL((topk_scan_kernel<SLOTS, VEC, true>), grid, block, 0, s, a);          \
         else hipLaunchKernelGGL((topk_scan_kernel<SLOTS, VEC, false>), grid, block, 0, s, a);                \
     } while (0)
-    if (k <= 64) {
-        if (vec4) RECO_TOPK_LAUNCH(1, 4);
-        else RECO_TOPK_LAUNCH(1, 1);
-    } else {
-        if (vec4) RECO_TOPK_LAUNCH(2, 4);
-        else RECO_TOPK_LAUNCH(2, 1);
+    {
+        ProfScope prof(s, RECO_PROF_TOPK);
+        if (k <= 64) {
+            if (vec4) RECO_TOPK_LAUNCH(1, 4);
+            else RECO_TOPK_LAUNCH(1, 1);
+        } else {
+            if (vec4) RECO_TOPK_LAUNCH(2, 4);
+            else RECO_TOPK_LAUNCH(2, 1);
+        }
     }
 #undef RECO_TOPK_LAUNCH
     RECO_CHECK_LAUNCH();
     if (a.splits > 1) {
         const int64_t mblocks = ceil_div64(rows, 4);
+        ProfScope prof(s, RECO_PROF_TOPK_MERGE);
         if (k <= 64)
             hipLaunchKernelGGL(topk_merge_kernel<1>, dim3((unsigned)mblocks), dim3(256), 0, s, a);
         else

@@ -979,7 +979,7 @@ int launch_tile_t(const TileArgs& a, hipStream_t s)
         if (n_cu <= 0) n_cu = 256;
     }
     const int64_t tiles = ceil_div64(a.N, TI) * ceil_div64(a.U, TUBX);
-    const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);   // one resident workgroup per CU
+    const unsigned grid = tile_grid(tiles, n_cu, a.reserve_cus);      // one resident workgroup per CU
     hipLaunchKernelGGL((tower_tile_kernel<G, L3, THREADS, TUBX>), dim3(grid), dim3(THREADS), lds, s, a);
     RECO_CHECK_LAUNCH();
     return RECO_OK;
@@ -1003,7 +1003,7 @@ int launch_tile_topk_t(const TileArgs& a, const TopkFuse& f, hipStream_t s)
         if (n_cu <= 0) n_cu = 256;
     }
     const int64_t tiles = ceil_div64(a.N, TI) * ceil_div64(a.U, TUBX);
-    const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);   // one resident workgroup per CU
+    const unsigned grid = tile_grid(tiles, n_cu, a.reserve_cus);      // one resident workgroup per CU
     hipLaunchKernelGGL((tower_tile_topk_kernel<G, L3, THREADS, TUBX, SLOTS>), dim3(grid), dim3(THREADS), lds, s, a, f);
     RECO_CHECK_LAUNCH();
     return RECO_OK;
@@ -1076,11 +1076,11 @@ int tower_launch_tile(int G, int has_l3, const float* img, const float* P, const
                       const float* EUg, const float* EIg, const int64_t* users, const int64_t* cands,
                       int64_t user_base, int64_t n_users, int64_t n_items, int64_t U, int64_t N,
                       float* out, int64_t ld_out, float bp, int act, float lo, float hi, int32_t* oob,
-                      unsigned int* next_tile, const float* l1, hipStream_t s)
+                      unsigned int* next_tile, const float* l1, int reserve_cus, hipStream_t s)
 {
     if (U <= 0 || N <= 0) return RECO_OK;
     RECO_REQUIRE(l1, "tower tile kernel: the layer-1 scale is missing");
-    TileArgs a{img, P, Q, EUg, EIg, users, cands, user_base, n_users, n_items, U, N, out, ld_out, bp, act, lo, hi, oob, next_tile, l1};
+    TileArgs a{img, P, Q, EUg, EIg, users, cands, user_base, n_users, n_items, U, N, out, ld_out, bp, act, lo, hi, oob, next_tile, l1, reserve_cus};
     if (G == 32 && has_l3) return launch_tile_t<32, true>(a, s);
     if (G == 0 && has_l3) return launch_tile_t<0, true>(a, s);
     if (G == 64 && !has_l3) return launch_tile_t<64, false>(a, s);
@@ -1164,13 +1164,13 @@ int tower_launch_tile_topk(int G, int has_l3, const float* img, const float* P, 
                            int64_t user_base, int64_t n_users, int64_t n_items, int64_t U, int64_t N,
                            float bp, int act, float lo, float hi, int32_t* oob,
                            int k, int v_max, unsigned int* counters, unsigned long long* partial,
-                           const float* l1, hipStream_t s)
+                           const float* l1, int reserve_cus, hipStream_t s)
 {
     if (U <= 0 || N <= 0) return RECO_OK;
     RECO_REQUIRE(l1, "fused top-k tile kernel: the layer-1 scale is missing");
     RECO_REQUIRE(k >= 1 && k <= 128 && v_max >= 1 && v_max <= 1024, "fused top-k: k=%d / v_max=%d out of range", k, v_max);
     RECO_REQUIRE(N < (1ll << 31) && ceil_div64(U, 16) < (1ll << 21), "fused top-k: problem too large for one launch");
-    TileArgs a{img, P, Q, EUg, EIg, users, cands, user_base, n_users, n_items, U, N, nullptr, 0, bp, act, lo, hi, oob, nullptr, l1};
+    TileArgs a{img, P, Q, EUg, EIg, users, cands, user_base, n_users, n_items, U, N, nullptr, 0, bp, act, lo, hi, oob, nullptr, l1, reserve_cus};
     const int64_t blocks = ceil_div64(U, tower_tile_users_per_block(G));
     TopkFuse f{k, v_max, counters, counters + 64, counters + 64 + blocks, partial};
     if (k <= 64) {

@@ -99,7 +99,18 @@ struct TileArgs {
     unsigned int* next_tile;   // work queue: tiles beyond the first gridDim.x are handed out through this counter (zeroed
                                // before the launch); null = static round-robin
     const float* l1;           // exact kernels: device words {s, 1/s}, the power-of-two scale P and Q were written with (below)
+    int reserve_cus;           // host side only: the persistent grid leaves this many CUs without a workgroup (tile_grid)
 };
+
+// Persistent tile kernels launch one workgroup per CU.  A handle can keep some CUs free (reco_tower_set_reserved_cus): the tile
+// kernels take 152 of a CU's 160 KB of LDS, so a kernel of another stream -- RCCL's all-gather of the previous step's lists --
+// otherwise finds no CU until a tile launch ends.  Work is handed out through a queue, so fewer workgroups only take more tiles each.
+inline unsigned tile_grid(int64_t tiles, int n_cu, int reserve_cus)
+{
+    int n = n_cu - (reserve_cus > 0 ? reserve_cus : 0);
+    if (n < 1) n = 1;
+    return (unsigned)(tiles < n ? tiles : n);
+}
 
 // ---- layer 1 as ONE instruction per element -------------------------------------------------------------------------------
 // x1 = relu(p + q) is an add and a max, 128 of the ~236 VALU instructions a wave issues per 160 MFMAs -- and beside f32 MFMAs

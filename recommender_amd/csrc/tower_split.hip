@@ -588,7 +588,7 @@ int launch_tile_split_t(const TileArgs& a, hipStream_t s)
         if (n_cu <= 0) n_cu = 256;
     }
     const int64_t tiles = ceil_div64(a.N, TI) * ceil_div64(a.U, TUB);
-    const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);
+    const unsigned grid = tile_grid(tiles, n_cu, a.reserve_cus);
     hipLaunchKernelGGL((tower_tile_split_kernel<G, L3>), dim3(grid), dim3(TILE_THREADS), lds, s, a);
     RECO_CHECK_LAUNCH();
     return RECO_OK;
@@ -645,11 +645,11 @@ int tower_launch_tile_split(int G, int has_l3, const void* img, const float* P, 
                             const float* EUg, const float* EIg, const int64_t* users, const int64_t* cands,
                             int64_t user_base, int64_t n_users, int64_t n_items, int64_t U, int64_t N,
                             float* out, int64_t ld_out, float bp, int act, float lo, float hi, int32_t* oob,
-                            unsigned int* next_tile, hipStream_t s)
+                            unsigned int* next_tile, int reserve_cus, hipStream_t s)
 {
     if (U <= 0 || N <= 0) return RECO_OK;
     TileArgs a{static_cast<const float*>(img), P, Q, EUg, EIg, users, cands, user_base, n_users, n_items, U, N, out, ld_out,
-               bp, act, lo, hi, oob, next_tile};
+               bp, act, lo, hi, oob, next_tile, nullptr, reserve_cus};
     if (G == 32 && has_l3) return launch_tile_split_t<32, true>(a, s);
     if (G == 0 && has_l3) return launch_tile_split_t<0, true>(a, s);
     if (G == 64 && !has_l3) return launch_tile_split_t<64, false>(a, s);

@@ -5,8 +5,14 @@ Tables and weights are replicated; every rank scores a contiguous user range aga
 the only data-path collective is ONE all-gather of the per-user top-k lists (k x 8 bytes per user: ids and scores travel
 in one packed int32 buffer).  With user sharding the lists are disjoint, so the "merge" is a concatenation in rank order.
 
-`TopkGather` keeps that collective off the critical path: the gather of step i runs on RCCL's stream while the scoring
-kernels of step i + 1 run on the compute stream (two packed buffers in flight).
+`TopkGather` keeps that collective off the critical path: the gather of step i is enqueued on RCCL's stream behind step i's
+top-k kernel, and the scoring kernels of step i + 1 are enqueued on the compute stream without waiting for it (two packed
+buffers in flight).  Where the gather kernel actually RUNS depends on the CUs: the persistent tile kernels hold 152 of 160 KB
+of LDS on every CU, so without a reservation RCCL's kernel starts in the gap between two tile launches (beside the small
+projection / select kernels) and a tile launch that finds a CU still busy simply starts that workgroup later -- tiles come from
+a work queue.  `reserve_cus` (or RECO_RESERVE_CUS) keeps that many CUs free of tile workgroups so the gather can run under a
+tile launch; it costs reserve/256 of the scoring throughput and is off by default.
+With ONE rank the lists are already complete: no collective is issued at all.
 
 Ordering of the collective behind the kernels that produce its input ("the round-1 hang"):
 RCCL ("nccl") launches the collective as a kernel on its own stream behind an event recorded on the caller's stream, so
@@ -30,6 +36,16 @@ class GatherTimeout(RuntimeError):
 
 def gather_timeout_s():
     return float(os.environ.get("RECO_GATHER_TIMEOUT_S", "60"))
+
+
+def reserved_cus_setting(value=None):
+    """CUs the tile kernels leave to the all-gather kernel: the argument, else RECO_RESERVE_CUS, else 0; within [0, 128]."""
+    if value is None:
+        value = os.environ.get("RECO_RESERVE_CUS", "0")
+    r = int(value)
+    if not 0 <= r <= 128:
+        raise ValueError("reserve_cus must be within [0, 128], got %d" % r)
+    return r
 
 
 def _stream_ordered(group=None):
@@ -106,8 +122,8 @@ def all_gather_topk(ids, vals, counts=None, group=None):
     counts: list of per-rank row counts (needed when they differ: ranks pad to the maximum and the padding is dropped
     after the gather).  ids / vals that are the two halves of packed_topk_buffers() are sent in place.
     """
-    if not dist.is_initialized():
-        return ids, vals
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return ids, vals                           # one rank: the concatenation of one shard is that shard
     world = dist.get_world_size(group)
     k = ids.shape[1]
     if counts is None:
@@ -134,7 +150,7 @@ def sharded_score_topk(model, k, total_users=None, candidates=None, group=None, 
     U = tower.n_users if total_users is None else int(total_users)
     start, count = shard_range(U, rank, world)
     ids, vals = tower.score_topk((start, count), k, candidates, None, check_ids=False, ws=ws, out=out)
-    if not dist.is_initialized():
+    if world == 1:
         return ids, vals
     counts = [shard_range(U, r, world)[1] for r in range(world)]
     return all_gather_topk(ids, vals, counts, group)
@@ -157,14 +173,18 @@ class TopkGather:
     watchdog (RCCL): see the module docstring.
     """
 
-    def __init__(self, model, k, total_users=None, candidates=None, group=None):
+    def __init__(self, model, k, total_users=None, candidates=None, group=None, reserve_cus=None):
         self.k, self.candidates, self.group = k, candidates, group
-        self.on = dist.is_initialized()
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.on = self.world > 1                       # one rank: nothing to gather, no collective is issued
         self.ordered = _stream_ordered(group)
         self.rank = dist.get_rank(group) if self.on else 0
-        self.world = dist.get_world_size(group) if self.on else 1
         self.device = model._compute_device()
         self.tower = model._tower(self.device)
+        # CUs kept free of tile workgroups while a gather may be in flight (module docstring); only meaningful with peers
+        self.reserve_cus = reserved_cus_setting(reserve_cus) if self.on else 0
+        if hasattr(self.tower, "set_reserved_cus") and (self.reserve_cus or getattr(self.tower, "reserved_cus", 0)):
+            self.tower.set_reserved_cus(self.reserve_cus)
         U = self.tower.n_users if total_users is None else int(total_users)
         self.start, self.count = shard_range(U, self.rank, self.world)
         self.counts = [shard_range(U, r, self.world)[1] for r in range(self.world)]

@@ -493,6 +493,12 @@ class Tower:
             self._L.reco_tower_destroy(h)
             self._h = None
 
+    def set_reserved_cus(self, cus):
+        """Leave `cus` CUs without a tile-kernel workgroup (reco_tower_set_reserved_cus): room for RCCL's all-gather kernel while a
+        persistent tile launch is in flight.  0 = use every CU (the default)."""
+        check(self._L.reco_tower_set_reserved_cus(self._h, int(cus)))
+        self.reserved_cus = int(cus)
+
     def _oob(self, check_ids):
         """Per-call counter of clamped ids (None: the caller validated its ids, nothing is counted and nothing synchronises)."""
         return torch.zeros(1, dtype=torch.int32, device=self.device) if check_ids else None

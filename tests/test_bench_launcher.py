@@ -52,11 +52,11 @@ def test_failed_or_hung_ranks_are_restarted_with_the_blocking_gather(monkeypatch
     def fake_run(cmd, env, timeout_s):
         calls.append(env.get("RECO_BENCH_SYNC_GATHER"))
         if len(calls) == 1:
-            return None, ""                                  # first attempt: hung until the limit
-        return 0, "banner\n" + json.dumps({"metric": "m", "value": 2.0, "n_gpus": 2}) + "\n"
+            return None, "", []                              # first attempt: hung until the limit, everything cleaned up
+        return 0, "banner\n" + json.dumps({"metric": "m", "value": 2.0, "n_gpus": 2}) + "\n", []
 
     monkeypatch.setattr(bench, "_run_children", fake_run)
-    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 2)
+    monkeypatch.setattr(bench, "visible_gpus", lambda: 2)
     monkeypatch.delenv("RECO_BENCH_SYNC_GATHER", raising=False)
     monkeypatch.delenv("RECO_BENCH_DRY_LAUNCH", raising=False)
     argv = ["--gpus", "2"]
@@ -67,5 +67,42 @@ def test_failed_or_hung_ranks_are_restarted_with_the_blocking_gather(monkeypatch
 
 
 def test_hung_children_are_killed_by_process_group():
-    rc, out = bench._run_children([sys.executable, "-c", "import time; print('x', flush=True); time.sleep(60)"], dict(os.environ), 1.0)
-    assert rc is None and out.strip() == "x"
+    rc, out, survivors = bench._run_children([sys.executable, "-c", "import time; print('x', flush=True); time.sleep(60)"], dict(os.environ), 1.0)
+    assert rc is None and out.strip() == "x" and survivors == []
+
+
+def test_hung_ranks_in_sessions_of_their_own_are_killed_too(tmp_path):
+    """torch elastic starts every rank with start_new_session=True: the ranks are not in the agent's process group.  A fake agent
+    that ignores SIGTERM and whose grandchild called setsid() must still leave nothing behind."""
+    pidfile = tmp_path / "rank.pid"
+    rank = "import os, time; os.setsid(); open(%r, 'w').write(str(os.getpid())); time.sleep(120)" % str(pidfile)
+    agent = ("import signal, subprocess, sys, time; signal.signal(signal.SIGTERM, signal.SIG_IGN); "
+             "subprocess.Popen([sys.executable, '-c', %r]); print('up', flush=True); time.sleep(120)" % rank)
+    rc, out, survivors = bench._run_children([sys.executable, "-c", agent], dict(os.environ), 3.0, grace_s=1.0)
+    assert rc is None and out.strip() == "up" and survivors == []
+    pid = int(pidfile.read_text())
+    assert not bench._alive(pid)
+
+
+def test_surviving_ranks_stop_the_retry(monkeypatch, capsys):
+    calls = []
+
+    def fake_run(cmd, env, timeout_s):
+        calls.append(1)
+        return None, "", [4242]
+
+    monkeypatch.setattr(bench, "_run_children", fake_run)
+    monkeypatch.setattr(bench, "visible_gpus", lambda: 2)
+    monkeypatch.delenv("RECO_BENCH_SYNC_GATHER", raising=False)
+    monkeypatch.delenv("RECO_BENCH_DRY_LAUNCH", raising=False)
+    argv = ["--gpus", "2"]
+    assert bench.self_launch(bench.parse_args(argv), argv) == 1
+    assert len(calls) == 1 and "survived" in capsys.readouterr().err
+
+
+def test_visible_gpus_reads_the_environment_before_anything_else(monkeypatch):
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0,1")
+    assert bench.visible_gpus() == 2
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpus() == 0

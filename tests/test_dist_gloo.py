@@ -123,3 +123,68 @@ def test_packed_buffers_are_sent_in_place():
     assert _is_packed(ids, vals) and _pack(ids, vals, 5).data_ptr() == buf.data_ptr()
     assert torch.equal(_pack(ids, vals, 5), buf)
     assert not _is_packed(ids.clone(), vals) and _pack(ids[:4], vals[:4], 5).shape == (2, 5, 3)
+
+
+class _ReservingTower(_StubTower):
+    reserved_cus = 0
+
+    def set_reserved_cus(self, cus):
+        self.reserved_cus = int(cus)
+
+
+def _reserve_worker(rank, world, port, total, k, q):
+    """The CU reservation reaches the tower only when there are peers to gather from; results do not depend on it."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RECO_RESERVE_CUS="6")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        by_arg, by_env = _ReservingTower(total, 50), _ReservingTower(total, 50)
+        pipe = TopkGather(_StubModel(by_arg), k, total, reserve_cus=4)
+        pipe_env = TopkGather(_StubModel(by_env), k, total)
+        ok = by_arg.reserved_cus == 4 and pipe.reserve_cus == 4 and by_env.reserved_cus == 6 and pipe_env.reserve_cus == 6
+        try:
+            TopkGather(_StubModel(_ReservingTower(total, 50)), k, total, reserve_cus=500)
+            ok = False
+        except ValueError:
+            pass
+        got = [pipe.step() for _ in range(3)] + [pipe.flush()]
+        u = torch.arange(total).view(-1, 1)
+        for step, (ids, vals) in enumerate(got[1:]):
+            ok = ok and torch.equal(ids, (u * 7 + torch.arange(k).view(1, -1) + step).to(torch.int32))
+        q.put((rank, bool(ok), tuple(got[-1][0].shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _single_rank_worker(rank, world, port, total, k, q):
+    """A process group of ONE rank (the driver's torchrun form at N = 1): no collective is issued, nothing is reserved."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RECO_RESERVE_CUS="6")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        calls = []
+        real = dist.all_gather_into_tensor
+        dist.all_gather_into_tensor = lambda *a, **kw: calls.append(1) or real(*a, **kw)
+        tower = _ReservingTower(total, 50)
+        pipe = TopkGather(_StubModel(tower), k, total)
+        got = [pipe.step() for _ in range(3)] + [pipe.flush()]
+        ok = got[0] is None and not pipe.on and tower.reserved_cus == 0 and tuple(got[-1][0].shape) == (total, k)
+        ids = torch.arange(total * k, dtype=torch.int32).view(total, k)
+        gi, gv = all_gather_topk(ids, ids.float())
+        ok = ok and gi is ids and not calls
+        q.put((rank, bool(ok), tuple(got[-1][0].shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cu_reservation_argument_and_environment_reach_the_tower():
+    for rank, ok, shape in _run(13, 10, _reserve_worker):
+        assert ok and shape == (13, 10)
+
+
+def test_single_rank_group_issues_no_collective():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_single_rank_worker, args=(0, 1, _free_port(), 9, 10, q))
+    p.start()
+    rank, ok, shape = q.get(timeout=120)
+    p.join(60)
+    assert p.exitcode == 0 and ok and shape == (9, 10)

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), "libreco_hip.so does not export %s" % name
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert L.reco_abi_version() == _lib.ABI_VERSION == 4
+    assert L.reco_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_tower_desc_layout_matches_header():

@@ -64,7 +64,7 @@ def _run(dev, world, rank, launched, upg, steps, warmup, precision):
         step(i)
     L = _lib.lib()
     cap = steps * (upg // 32 + 2) + 4                 # one tile-kernel launch per user chunk (split mode: 240 users at 1 M items)
-    _lib.check(L.reco_profile_enable(cap))
+    _lib.check(L.reco_profile_enable_kinds(cap, 1 << _lib.PROF_TOWER))
     fence()
     t0 = time.perf_counter()
     for i in range(steps):
