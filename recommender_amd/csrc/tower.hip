@@ -279,21 +279,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
                     __device__ __forceinline__ f32x4 passthrough(const PQ& v) const { return v.q; }
                     const float* grow;     // this pair's GMF item row half in LDS
                     const f32x4* gu;       // the user's GMF row half, predict weights folded in
-                    __device__ __forceinline__ float between() const
-                    {
-                        float part = 0.f;
-                        if constexpr (G > 0) {
-#pragma unroll
-                            for (int c = 0; c < G / 8; ++c) {
-                                const f32x4 gi = *reinterpret_cast<const f32x4*>(grow + 4 * c);
-                                part = fmaf(gu[c].x, gi.x, part);
-                                part = fmaf(gu[c].y, gi.y, part);
-                                part = fmaf(gu[c].z, gi.z, part);
-                                part = fmaf(gu[c].w, gi.w, part);
-                            }
-                        }
-                        return part;
-                    }
+                    __device__ __forceinline__ float between() const { return gmf_half_tile<G>(grow, gu); }
                 };
                 const float part = tower_mlp_part<L3>(s_img, lane, X1TileLds{qrow, s_p + uu * H1 + 4 * h, s_g + (g * 32 + j) * GS + h * (G / 2), gu});
                 const float total = part + __shfl_xor(part, 32) + a.bp;
@@ -545,21 +531,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_topk_kernel
                     __device__ __forceinline__ f32x4 passthrough(const PQ& v) const { return v.q; }
                     const float* grow;     // this pair's GMF item row half in LDS
                     const f32x4* gu;       // the user's GMF row half, predict weights folded in
-                    __device__ __forceinline__ float between() const
-                    {
-                        float part = 0.f;
-                        if constexpr (G > 0) {
-#pragma unroll
-                            for (int c = 0; c < G / 8; ++c) {
-                                const f32x4 gi = *reinterpret_cast<const f32x4*>(grow + 4 * c);
-                                part = fmaf(gu[c].x, gi.x, part);
-                                part = fmaf(gu[c].y, gi.y, part);
-                                part = fmaf(gu[c].z, gi.z, part);
-                                part = fmaf(gu[c].w, gi.w, part);
-                            }
-                        }
-                        return part;
-                    }
+                    __device__ __forceinline__ float between() const { return gmf_half_tile<G>(grow, gu); }
                 };
                 const float part = tower_mlp_part<L3>(s_img, lane, X1TileLds{qrow, s_p + uu * H1 + 4 * h, s_g + (g * 32 + j) * GS + h * (G / 2), gu});
                 const float sc = epilogue(part + __shfl_xor(part, 32) + a.bp, a.act, a.lo, a.hi);
@@ -610,8 +582,8 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_topk_kernel
 template <int G, bool L3, int WAVES, bool BIG, bool CLAMP>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_kernel(PairArgs a)
 {
-    constexpr int GS = G + 4;
-    constexpr int WAVE_FLOATS = 32 * HS + (G > 0 ? 32 * GS : 0);
+    constexpr int GC = G / 4;                                    // GMF column sums per pair (tower_shared.h)
+    constexpr int WAVE_FLOATS = 32 * HS + 32 * GC;
     constexpr int NG = G > 0 ? (32 * (G / 4)) / 64 : 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_img = smem;
@@ -621,7 +593,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_kernel(Pair
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     float* s_x = smem + LDS_IMG_SIZE<L3> + wave * WAVE_FLOATS;   // [32][HS]  relu(P+Q), one K half of this wave's pairs
-    float* s_gp = s_x + 32 * HS;                          // [32][GS]  gmf products
+    float* s_gp = s_x + 32 * HS;                          // [32][GC]  gmf column sums
 
     load_image_scaled<L3, 64 * WAVES>(s_img, a.img, tid, CLAMP ? layer1_scale(a.l1) : Layer1Scale{1.f, 1.f});
     __syncthreads();
@@ -647,7 +619,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_kernel(Pair
         const int64_t base = grp * 32;
         const bool more = grp + stride < ngroups;
         pair_store_half<CLAMP>(s_x, lane, pf, qf);
-        if constexpr (G > 0) pair_store_gmf<G>(s_gp, lane, gu, gi);
+        if constexpr (G > 0) pair_store_gmf_cols<G>(s_gp, lane, gu, gi, s_img + lds_img<L3>(IMG_WPG));
         __builtin_amdgcn_wave_barrier();
         // the second half (ps / qs) still belongs to THIS group: the next group's ids wait in other registers until it is stored
         int nu2 = 0, ni2 = 0;
@@ -681,21 +653,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_kernel(Pair
             __device__ __forceinline__ float between() const { return 0.f; }
         };
         float part = tower_mlp_part<L3>(s_img, lane, X1Pair{a, xrow, s_x, ps, qs, nu2, ni2, lane, more});
-        if constexpr (G > 0) {
-            const float* grow = s_gp + j * GS + h * (G / 2);
-            const float* wpg = s_img + lds_img<L3>(IMG_WPG) + h * (G / 2);
-            float gm = 0.f;                                    // summed on its own, as in the tile kernels (tower_mlp_part)
-#pragma unroll
-            for (int c = 0; c < G / 8; ++c) {
-                const f32x4 gp = *reinterpret_cast<const f32x4*>(grow + 4 * c);
-                const f32x4 w = *reinterpret_cast<const f32x4*>(wpg + 4 * c);
-                gm = fmaf(gp.x, w.x, gm);
-                gm = fmaf(gp.y, w.y, gm);
-                gm = fmaf(gp.z, w.z, gm);
-                gm = fmaf(gp.w, w.w, gm);
-            }
-            part = gm + part;
-        }
+        if constexpr (G > 0) part = gmf_half_pair<G>(s_gp, j, h) + part;    // summed on its own, as in the tile kernels
         const float total = part + __shfl_xor(part, 32) + a.bp;
         const int64_t b = base + j;
         if (h == 0 && b < a.B) a.out[b] = epilogue(total, a.act, a.lo, a.hi);
@@ -710,8 +668,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_kernel(Pair
 template <int G, bool L3, int WAVES, bool BIG, bool CLAMP, int LOOK>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_q_kernel(PairArgs a)
 {
-    constexpr int GS = G + 4;
-    constexpr int WAVE_FLOATS = 32 * QSP + (G > 0 ? 32 * GS : 0);
+    constexpr int GC = G / 4;                                    // GMF column sums per pair (tower_shared.h)
+    constexpr int WAVE_FLOATS = 32 * QSP + 32 * GC;
     constexpr int NG = G > 0 ? (32 * (G / 4)) / 64 : 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_img = smem;
@@ -721,7 +679,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_q_kernel(Pa
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     float* s_x = smem + LDS_IMG_SIZE<L3> + wave * WAVE_FLOATS;   // [32][QSP]  one K quarter of this wave's layer-1 activations
-    float* s_gp = s_x + 32 * QSP;                                // [32][GS]   gmf products
+    float* s_gp = s_x + 32 * QSP;                                // [32][GC]   gmf column sums
 
     load_image_scaled<L3, 64 * WAVES>(s_img, a.img, tid, CLAMP ? layer1_scale(a.l1) : Layer1Scale{1.f, 1.f});
     __syncthreads();
@@ -744,7 +702,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_q_kernel(Pa
         const int64_t base = grp * 32;
         const bool more = grp + stride < ngroups;
         pair_store_quarter<CLAMP>(s_x, lane, p0, q0);                      // quarter 0
-        if constexpr (G > 0) pair_store_gmf<G>(s_gp, lane, gu, gi);
+        if constexpr (G > 0) pair_store_gmf_cols<G>(s_gp, lane, gu, gi, s_img + lds_img<L3>(IMG_WPG));
         __builtin_amdgcn_wave_barrier();
         pair_load_quarter<BIG>(a, nu, ni, lane, LOOK, p0, q0);             // quarter 2 (1) of THIS group
         int nu2 = 0, ni2 = 0;
@@ -796,21 +754,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void tower_pairs_q_kernel(Pa
             __device__ __forceinline__ float between() const { return 0.f; }
         };
         float part = tower_mlp_part<L3>(s_img, lane, X1Quarter{a, xrow, s_x, p0, q0, p1, q1, nu, ni, nu2, ni2, lane, more});
-        if constexpr (G > 0) {
-            const float* grow = s_gp + j * GS + h * (G / 2);
-            const float* wpg = s_img + lds_img<L3>(IMG_WPG) + h * (G / 2);
-            float gm = 0.f;
-#pragma unroll
-            for (int c = 0; c < G / 8; ++c) {
-                const f32x4 gp = *reinterpret_cast<const f32x4*>(grow + 4 * c);
-                const f32x4 w = *reinterpret_cast<const f32x4*>(wpg + 4 * c);
-                gm = fmaf(gp.x, w.x, gm);
-                gm = fmaf(gp.y, w.y, gm);
-                gm = fmaf(gp.z, w.z, gm);
-                gm = fmaf(gp.w, w.w, gm);
-            }
-            part = gm + part;
-        }
+        if constexpr (G > 0) part = gmf_half_pair<G>(s_gp, j, h) + part;
         const float total = part + __shfl_xor(part, 32) + a.bp;
         const int64_t b = base + j;
         if (h == 0 && b < a.B) a.out[b] = epilogue(total, a.act, a.lo, a.hi);
@@ -1026,7 +970,7 @@ int launch_pairs_tb(const PairArgs& a, hipStream_t s)
         // 100 per user), quarters two in flight 2.38 / 1.99, one in flight 2.34 / 1.93 <- this, 12 waves 2.80 / 2.21.
         // The Hybrid shape (its 64-wide GMF rows fill the LDS at 8 waves; measured level) stays on the half-staged kernel.
         constexpr int WAVES = BIG ? 8 : 12, LOOK = 1;
-        constexpr size_t lds = (size_t)(LDS_IMG_SIZE<L3> + WAVES * (32 * QSP + (G > 0 ? 32 * (G + 4) : 0))) * sizeof(float);
+        constexpr size_t lds = (size_t)(LDS_IMG_SIZE<L3> + WAVES * (32 * QSP + 32 * (G / 4))) * sizeof(float);
         static_assert(lds <= 160 * 1024, "pair kernel LDS budget");
         static bool attr[RECO_MAX_DEVICES] = {};
         if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&tower_pairs_q_kernel<G, L3, WAVES, BIG, CLAMP, LOOK>), lds, attr)) return rc;
@@ -1037,7 +981,7 @@ int launch_pairs_tb(const PairArgs& a, hipStream_t s)
         return RECO_OK;
     } else {
         constexpr int WAVES = G <= 32 ? 8 : 4;
-        constexpr size_t lds = (size_t)(LDS_IMG_SIZE<L3> + WAVES * (32 * HS + (G > 0 ? 32 * (G + 4) : 0))) * sizeof(float);
+        constexpr size_t lds = (size_t)(LDS_IMG_SIZE<L3> + WAVES * (32 * HS + 32 * (G / 4))) * sizeof(float);
         static_assert(lds <= 160 * 1024, "pair kernel LDS budget");
         static bool attr[RECO_MAX_DEVICES] = {};
         if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&tower_pairs_kernel<G, L3, WAVES, BIG, CLAMP>), lds, attr)) return rc;

@@ -454,6 +454,62 @@ __device__ __forceinline__ void pair_load_gmf(const PairArgs& a, int my_u, int m
     }
 }
 
+// ---- the GMF half of the predict layer, summed the SAME way in every exact kernel -----------------------------------------
+// so that forward(u, i) (pair kernels) and score_matrix()[u, i] / score_topk (tile kernels) return the same bits:
+//   per float4 column c of the G-wide rows:  s_c = fma(uw.w, i.w, fma(uw.z, i.z, fma(uw.y, i.y, uw.x * i.x))),  uw = u (*) w_predict[:G]
+//   per half h (lane >> 5) of the row:       gmf_h = ((s_c0 + s_c0+1) + ...) + s_c0+G/8-1   in column order
+// Tile kernels hold uw per user (one multiply per user, not per pair) and read the item row from LDS; pair kernels compute s_c in
+// the lane that still holds column c of both rows in its staging registers and stage ONE float per (pair, column) -- [32][G/4]
+// floats per wave instead of the [32][G+4] products -- which the MFMA body's lane adds up.
+__device__ __forceinline__ float gmf_col(f32x4 uw, f32x4 i)
+{
+    float s = uw.x * i.x;
+    s = fmaf(uw.y, i.y, s);
+    s = fmaf(uw.z, i.z, s);
+    return fmaf(uw.w, i.w, s);
+}
+
+// tile kernels: grow = this pair's item row half in LDS, gu = the user's row half times the predict weights
+template <int G>
+__device__ __forceinline__ float gmf_half_tile(const float* grow, const f32x4* gu)
+{
+    float part = 0.f;
+    if constexpr (G > 0) {
+        part = gmf_col(gu[0], *reinterpret_cast<const f32x4*>(grow));
+#pragma unroll
+        for (int c = 1; c < G / 8; ++c) part = part + gmf_col(gu[c], *reinterpret_cast<const f32x4*>(grow + 4 * c));
+    }
+    return part;
+}
+
+// pair kernels, staging side: lane holds float4 column e % C of rows e / C (e = it * 64 + lane) of both tables; wpg = predict weights
+// of the GMF half (LDS).  s_gs [32][C] floats.
+template <int G>
+__device__ __forceinline__ void pair_store_gmf_cols(float* s_gs, int lane, const f32x4* gu, const f32x4* gi, const float* wpg)
+{
+    constexpr int C = G / 4, NG = (32 * C) / 64;
+    const f32x4 w = *reinterpret_cast<const f32x4*>(wpg + 4 * (lane % C));       // e % C == lane % C: 64 is a multiple of C
+#pragma unroll
+    for (int it = 0; it < NG; ++it) s_gs[it * 64 + lane] = gmf_col(gu[it] * w, gi[it]);
+}
+
+// pair kernels, MFMA-body side: pair j's half h
+template <int G>
+__device__ __forceinline__ float gmf_half_pair(const float* s_gs, int j, int h)
+{
+    constexpr int C = G / 4;
+    static_assert((C / 2) % 4 == 0, "a half row's column sums are read as float4");
+    const f32x4* r = reinterpret_cast<const f32x4*>(s_gs + j * C + h * (C / 2));
+    f32x4 v = r[0];
+    float part = ((v.x + v.y) + v.z) + v.w;
+#pragma unroll
+    for (int n = 1; n < C / 8; ++n) {
+        v = r[n];
+        part = (((part + v.x) + v.y) + v.z) + v.w;
+    }
+    return part;
+}
+
 template <int G>
 __device__ __forceinline__ void pair_store_gmf(float* s_gp, int lane, const f32x4* gu, const f32x4* gi)
 {
