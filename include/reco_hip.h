@@ -207,8 +207,13 @@ int reco_tower_score_pairs(reco_tower_t* t, const int64_t* user, const int64_t* 
  * pair b) -- the Hybrid forward, where every pair brings its own encoder latents
  * (evaluate_hybridautorecncf_rating.py:197-208).  u_gmf/i_gmf [B,dg], u_mlp/i_mlp [B,dm];
  * for the Hybrid head pass the same latent matrix for gmf and mlp.  The handle may have been
- * created without tables (n_users = n_items = 0). */
+ * created without tables (n_users = n_items = 0).
+ * Hybrid head shape (dg = dm = 64, two layers) in RECO_PREC_F32 with u_gmf == u_mlp and i_gmf == i_mlp (what
+ * HybridAutoRecNCF.forward passes): ONE kernel runs both MLP layers and the GMF product out of the 512 B of latents per pair
+ * (tower_rows.hip); no projection buffers, ws may be NULL -- reco_tower_rows_workspace_bytes_for() then returns 0.  Any other
+ * call first writes the layer-1 projections [B,128] x 2 into ws (reco_tower_rows_workspace_bytes(B)). */
 size_t reco_tower_rows_workspace_bytes(int64_t B);
+size_t reco_tower_rows_workspace_bytes_for(const reco_tower_t* t, int gmf_rows_are_mlp_rows, int64_t B);
 int reco_tower_score_rows(reco_tower_t* t, const float* u_gmf, const float* i_gmf,
                           const float* u_mlp, const float* i_mlp, int64_t B, float* out,
                           void* ws, size_t ws_bytes, void* stream);

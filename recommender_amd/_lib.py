@@ -54,6 +54,7 @@ _SIGNATURES = {
     "reco_tower_set_reserved_cus": (c_int, [c_void_p, c_int]),
     "reco_tower_score_pairs": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "reco_tower_rows_workspace_bytes": (c_size_t, [c_int64]),
+    "reco_tower_rows_workspace_bytes_for": (c_size_t, [c_void_p, c_int, c_int64]),
     "reco_tower_score_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                       c_void_p, c_size_t, c_void_p]),
     "reco_tower_matrix_workspace_bytes": (c_size_t, [c_int64, c_int64]),

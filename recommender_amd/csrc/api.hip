@@ -34,6 +34,11 @@ int tower_launch_pairs_split(int G, int has_l3, const void* img, const float* P,
                              const float* EUg, const float* EIg, const int64_t* user, const int64_t* item,
                              int64_t n_users, int64_t n_items, int64_t B, float* out, float bp, int act,
                              float lo, float hi, int32_t* oob, hipStream_t s);
+// launchers defined in tower_rows.hip (the Hybrid head over pair rows, layer 1 inside the kernel)
+size_t tower_rows_image_bytes();
+int tower_pack_rows_image(const float* W1, const float* b1, float* img1, hipStream_t s);
+int tower_launch_rows(const float* img, const float* img1, const float* zu, const float* zi, int64_t B, float* out,
+                      float bp, int act, float lo, float hi, hipStream_t s);
 int tower_tile_users_per_block(int G);
 size_t tower_topk_counter_bytes(int G, int64_t U);
 int tower_launch_tile_topk(int G, int has_l3, const float* img, const float* P, const float* Q,
@@ -243,6 +248,7 @@ struct reco_tower {
     float bp;
     float* img;       // packed weight image [IMG_SIZE]
     void* img_split;  // bf16x3 image (RECO_PREC_SPLIT_BF16X3 only)
+    float* img1;      // layer-1 image of the pair-row kernel (tower_rows.hip): exact Hybrid head shape (dg = dm = 64, two layers) only
     float* P;         // [n_users,128] layer-1 user projection (+ b1)
     float* Q;         // [n_items,128] layer-1 item projection
     float* l1;        // device words {s, 1/s}: the power of two layer 1 is scaled by (tower_shared.h), fixed by the handle's tables;
@@ -300,6 +306,7 @@ extern "C" void reco_tower_destroy(reco_tower_t* t)
     if (!t) return;
     (void)hipFree(t->img);
     (void)hipFree(t->img_split);
+    (void)hipFree(t->img1);
     (void)hipFree(t->P);
     (void)hipFree(t->Q);
     (void)hipFree(t->l1);
@@ -358,6 +365,8 @@ extern "C" int reco_tower_create(const reco_tower_desc_t* d, void* stream, reco_
     if (t->mfma) e = hipMalloc(&t->img, IMG_SIZE * sizeof(float));
     const bool split = t->mfma && d->precision == RECO_PREC_SPLIT_BF16X3;
     if (e == hipSuccess && split) e = hipMalloc(&t->img_split, tower_split_image_bytes(t->has_l3));
+    const bool rows_kernel = t->mfma && !split && d->n_layers == 2 && d->dg == 64 && d->dm == 64;
+    if (e == hipSuccess && rows_kernel) e = hipMalloc(&t->img1, tower_rows_image_bytes());
     if (e == hipSuccess && t->mfma && tables) e = hipMalloc(&t->P, (size_t)d->n_users * H1 * sizeof(float));
     if (e == hipSuccess && t->mfma && tables) e = hipMalloc(&t->Q, (size_t)d->n_items * H1 * sizeof(float));
     if (e == hipSuccess && t->mfma && tables && !split) e = hipMalloc(&t->l1, 256);
@@ -370,6 +379,7 @@ extern "C" int reco_tower_create(const reco_tower_desc_t* d, void* stream, reco_
     if (t->mfma) {
         rc = tower_pack_image(d->W[1], d->b[1], t->has_l3 ? d->W[2] : nullptr, t->has_l3 ? d->b[2] : nullptr,
                               d->w_predict, t->G, t->has_l3, t->img, s);
+        if (!rc && t->img1) rc = tower_pack_rows_image(d->W[0], d->b[0], t->img1, s);
         if (!rc && split)
             rc = tower_pack_split_image(d->W[1], t->has_l3 ? d->W[2] : nullptr, t->has_l3, t->img, t->img_split, s);
         if (!rc && tables && t->l1)       // the layer-1 scale of every pair these tables can form, before anything is projected
@@ -430,6 +440,18 @@ extern "C" size_t reco_tower_rows_workspace_bytes(int64_t B)
     return B > 0 ? 2 * align_up((size_t)B * H1 * sizeof(float), 256) : 0;
 }
 
+// the pair-row kernel with layer 1 inside (tower_rows.hip): exact Hybrid head whose GMF and MLP rows are the same latents
+static bool rows_fused(const reco_tower* t, const float* u_gmf, const float* i_gmf, const float* u_mlp, const float* i_mlp)
+{
+    return t->img1 && u_gmf == u_mlp && i_gmf == i_mlp && u_mlp && i_mlp;
+}
+
+extern "C" size_t reco_tower_rows_workspace_bytes_for(const reco_tower_t* t, int gmf_rows_are_mlp_rows, int64_t B)
+{
+    if (t && t->img1 && gmf_rows_are_mlp_rows) return 0;
+    return reco_tower_rows_workspace_bytes(B);
+}
+
 extern "C" int reco_tower_score_rows(reco_tower_t* t, const float* u_gmf, const float* i_gmf,
                                      const float* u_mlp, const float* i_mlp, int64_t B, float* out,
                                      void* ws, size_t ws_bytes, void* stream)
@@ -447,6 +469,10 @@ extern "C" int reco_tower_score_rows(reco_tower_t* t, const float* u_gmf, const 
         return gmf_launch_pairs(u_gmf, i_gmf, d.w_predict, nullptr, nullptr, B, B, B, d.dg, out, t->bp, d.act, d.lo,
                                 d.hi, nullptr, s);
     RECO_REQUIRE(u_mlp && i_mlp, "score_rows: MLP rows missing");
+    if (rows_fused(t, u_gmf, i_gmf, u_mlp, i_mlp)) {      // no projections, no workspace: the latents are the only traffic
+        ProfScope prof(s, RECO_PROF_TOWER);
+        return tower_launch_rows(t->img, t->img1, u_mlp, i_mlp, B, out, t->bp, d.act, d.lo, d.hi, s);
+    }
     const size_t half = align_up((size_t)B * H1 * sizeof(float), 256);
     if (!ws || ws_bytes < 2 * half) { reco_set_error("score_rows: workspace too small (%zu < %zu)", ws_bytes, 2 * half); return RECO_ENOMEM; }
     float* P = static_cast<float*>(ws);

@@ -528,8 +528,10 @@ class Tower:
                 raise ValueError("%s must be a [%d, %d] float32 tensor on %s, got %s"
                                  % (name, B, width, self.device, None if t is None else tuple(t.shape)))
         out = torch.empty(B, dtype=torch.float32, device=self.device)
-        nbytes = self._L.reco_tower_rows_workspace_bytes(B)
-        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.device)
+        same = (tens[0] is not None and tens[2] is not None and tens[0].data_ptr() == tens[2].data_ptr()
+                and tens[1].data_ptr() == tens[3].data_ptr())            # the Hybrid forward: GMF and MLP rows are the same latents
+        nbytes = self._L.reco_tower_rows_workspace_bytes_for(self._h, 1 if same else 0, B)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device) if nbytes else None
         with torch.cuda.device(self.device):
             check(self._L.reco_tower_score_rows(self._h, _p(tens[0]), _p(tens[1]), _p(tens[2]), _p(tens[3]), B, _p(out),
                                                 _p(ws), nbytes, _stream(self.device)))

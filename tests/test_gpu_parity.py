@@ -212,6 +212,44 @@ def test_g4_hybrid(g4, tower_precision):
         assert np.array_equal(ids.cpu().numpy(), oid) and np.array_equal(vals.cpu().numpy(), oval)
 
 
+@pytest.mark.parametrize("rating", [True, False])
+def test_hybrid_forward_pair_rows_kernel_with_layer1_inside(g4, rating):
+    """HybridAutoRecNCF.forward's head (evaluate_hybridautorecncf_rating.py:167-184) runs as ONE kernel when the GMF and MLP rows are
+    the same latents (tower_rows.hip): every batch size class around the 32-pair group and the 8-wave workgroup, against the
+    oracle's head in fp32 and fp64, against the two-GEMM + pair-kernel path (forced by handing the GMF rows in as copies), and
+    with no workspace at all."""
+    import ctypes
+    from recommender_amd import _lib
+    from recommender_amd.hybridautorecncf.model import HybridAutoRecNCF
+    tag = "rating" if rating else "logit"
+    sd = golden_sd(g4, tag)
+    U, I, hd = ((83, 47), (40, 26))[0 if rating else 1] + (((48, 40), (256, 128))[0 if rating else 1],)
+    m = HybridAutoRecNCF(U, I, 64, [128, 64], hidden_dims=hd, rating_output=rating)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.eval().cuda()
+    dev = torch.device("cuda", 0)
+    t = m.ncf._tower(dev)
+    rng = np.random.default_rng(3)
+    for B in (1, 31, 32, 33, 255, 256, 257, 5000, 70001):
+        zu = (rng.standard_normal((B, 64)) * 0.7).astype(np.float32); zi = (rng.standard_normal((B, 64)) * 0.7).astype(np.float32)
+        zud, zid = torch.from_numpy(zu).cuda(), torch.from_numpy(zi).cuda()
+        got = t.score_rows(zud, zid, zud, zid)
+        assert t._L.reco_tower_rows_workspace_bytes_for(t._h, 1, B) == 0
+        assert_close(got.cpu().numpy(), O.hybrid_head(sd, zu, zi, np.float32, rating=rating), atol=2e-6, what="rows kernel B=%d" % B)
+        assert_close(got.cpu().numpy(), O.hybrid_head(sd, zu, zi, np.float64, rating=rating), atol=2e-6, what="rows kernel B=%d vs fp64" % B)
+        unfused = t.score_rows(zud.clone(), zid.clone(), zud, zid)          # other pointers for the GMF rows: projections + pair kernel
+        assert_close(got.cpu().numpy(), unfused.cpu().numpy(), atol=2e-6, what="rows kernel vs unfused B=%d" % B)
+    # through the module: forward(user_z, item_z)
+    pred = m.ncf(zud, zid)
+    assert torch.equal(pred, got)
+    # straight through the C ABI with a NULL workspace
+    out = torch.empty(B, dtype=torch.float32, device=dev)
+    rc = t._L.reco_tower_score_rows(t._h, ctypes.c_void_p(zud.data_ptr()), ctypes.c_void_p(zid.data_ptr()), ctypes.c_void_p(zud.data_ptr()),
+                                    ctypes.c_void_p(zid.data_ptr()), B, ctypes.c_void_p(out.data_ptr()), None, 0,
+                                    ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    assert rc == 0 and torch.equal(out, got)
+
+
 def test_topk_properties_long_rows_and_masks():
     from recommender_amd import ops
     rng = np.random.default_rng(11)
