@@ -134,6 +134,19 @@ int reco_csr_linear_f32(const int64_t* row_ptr, const int32_t* col, const float*
 /* out[c, r] = in[r, c]  (weight layout for reco_csr_linear_f32; no counterpart in the reference) */
 int reco_transpose_f32(const float* in, int64_t rows, int64_t cols, int64_t ld_in, float* out, int64_t ld_out, void* stream);
 
+/* Two consecutive narrow Linear layers in one launch:  C = act3( act2( X W2^T + b2 ) W3^T + b3 )
+ * replaces the two narrow layers of the Hybrid model's encoders / decoders (Linear+ReLU, Linear)
+ *   src/hybridautorecncf/evaluate_hybridautorecncf_rating.py:78-89 (encoder.3, encoder.6), :94-106 (decoder.0, decoder.3)
+ * whose [rows, N2] intermediate stays in LDS.  X [M, K1] (row stride ldx), W2 [N2, K1], W3 [N3, N2] as nn.Linear stores them;
+ * b2 / b3 nullable; lo / hi serve both activations.  Widths: reco_mlp2_supported(K1, N2, N3) != 0 (K1 a multiple of 8 up to 512,
+ * N2 and N3 multiples of 32, both row tiles within 96 KB of LDS); everything 16-byte aligned, ldx / ldc multiples of 4.
+ * Results equal two reco_linear_f32 calls bit for bit (same k-ordered chain, bias added after it). */
+int reco_mlp2_supported(int64_t K1, int64_t N2, int64_t N3);
+int reco_mlp2_f32(const float* X, int64_t ldx, int64_t M, int64_t K1,
+                  const float* W2, const float* b2, int64_t N2, int act2,
+                  const float* W3, const float* b3, int64_t N3, int act3, float lo, float hi,
+                  float* C, int64_t ldc, void* stream);
+
 /* AutoRec forward: out = act( sigmoid(X We^T + be) Wd^T + bd )        src/autorec/utils/model.py:31-33
  * X [B, n_in], We [hidden, n_in], Wd [n_in, hidden], hidden_ws [B, hidden] (caller scratch),
  * out [B, n_in].  act = RECO_ACT_NONE (the module's forward) or RECO_ACT_CLAMP with lo/hi

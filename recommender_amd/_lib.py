@@ -46,6 +46,9 @@ _SIGNATURES = {
                                     c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_float, c_float,
                                     c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     "reco_transpose_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "reco_mlp2_supported": (c_int, [c_int64, c_int64, c_int64]),
+    "reco_mlp2_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_int,
+                              c_float, c_float, c_void_p, c_int64, c_void_p]),
     "reco_autorec_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "reco_autorec_forward": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                      c_int, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -59,7 +59,8 @@ class AutoRec(nn.Module):
         ships to the device as the encoder's only input form.  Returns the CsrMatrix."""
         device = self._device_of(train_matrix)
         m = train_matrix.to(device=device, dtype=torch.float32).contiguous()
-        csr = ops.CsrMatrix.from_dense(m, transpose=self.item_based)
+        k_dim = m.shape[0] if self.item_based else m.shape[1]
+        csr = ops.CsrMatrix.from_dense(m, transpose=self.item_based, k_ranges=ops.csr_k_ranges(k_dim, self.num_hidden_units))
         _csr_cache[self] = (_matrix_key(m), csr)
         return csr
 

@@ -67,7 +67,9 @@ class AutoEncoder(nn.Module):
         """x: dense [batch, in] tensor, or an ops.CsrMatrix of the batch (first layer over the observed entries only)."""
         device = x.device
         weights = self._device_weights(seq, device)
-        for n, (w, b) in enumerate(weights):
+        n = 0
+        while n < len(weights):
+            w, b = weights[n]
             last = n + 1 == len(weights)
             act = final_act if last else "relu"
             if n == 0 and isinstance(x, ops.CsrMatrix):
@@ -77,8 +79,16 @@ class AutoEncoder(nn.Module):
                     wt = (w, ops.transpose(w))
                     cache[("T", id(seq))] = wt
                 x = ops.csr_linear(x, wt[1], b, act=act)
+                n += 1
+            elif (not last and not (transposed and n == 0) and w.shape[1] <= 512
+                  and ops.mlp2_supported(w.shape[1], w.shape[0], weights[n + 1][0].shape[0])):
+                # two narrow layers in one launch, the intermediate stays in LDS (reco_mlp2_f32; same bits as two linear calls)
+                w3, b3 = weights[n + 1]
+                x = ops.mlp2(x, w, b, w3, b3, "relu", final_act if n + 2 == len(weights) else "relu")
+                n += 2
             else:
                 x = ops.linear(x, w, b, act=act, x_transposed=(transposed and n == 0))
+                n += 1
         return x
 
     def _prep(self, x):
@@ -191,7 +201,10 @@ class HybridAutoRecNCF(nn.Module):
         ops.require_gpu()
         device = rating_matrix.device if rating_matrix.is_cuda else torch.device("cuda", torch.cuda.current_device())
         R = rating_matrix.to(device=device, dtype=torch.float32).contiguous()
-        pair = (ops.CsrMatrix.from_dense(R), ops.CsrMatrix.from_dense(R, transpose=True))
+        wide_u = next(m for m in self.user_autorec.encoder if isinstance(m, nn.Linear)).out_features
+        wide_i = next(m for m in self.item_autorec.encoder if isinstance(m, nn.Linear)).out_features
+        pair = (ops.CsrMatrix.from_dense(R, k_ranges=ops.csr_k_ranges(R.shape[1], wide_u)),
+                ops.CsrMatrix.from_dense(R, transpose=True, k_ranges=ops.csr_k_ranges(R.shape[0], wide_i)))
         _csr_cache[self] = ((R.data_ptr(), R._version, tuple(R.shape), str(R.device)), pair)
         return pair
 

@@ -141,6 +141,30 @@ def linear(x, weight, bias=None, act=None, lo=0.0, hi=0.0, out=None, x_transpose
     return out
 
 
+def mlp2_supported(k1, n2, n3):
+    return bool(_lib.lib().reco_mlp2_supported(int(k1), int(n2), int(n3)))
+
+
+def mlp2(x, w2, b2, w3, b3, act2="relu", act3=None, lo=0.0, hi=0.0):
+    """act3(act2(x @ w2.T + b2) @ w3.T + b3) in one launch (reco_mlp2_f32): two narrow Linear layers whose intermediate stays in
+    LDS.  Same bits as two linear() calls.  Check mlp2_supported(K1, N2, N3) first."""
+    if not (isinstance(x, torch.Tensor) and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1
+            and x.stride(0) >= x.shape[1] and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0):
+        x = _f32(x, "input", 2)
+    w2 = _f32(w2, "w2", 2); w3 = _f32(w3, "w3", 2)
+    b2 = None if b2 is None else _f32(b2, "b2", 1)
+    b3 = None if b3 is None else _f32(b3, "b3", 1)
+    M, K1 = x.shape
+    N2, N3 = w2.shape[0], w3.shape[0]
+    if w2.shape[1] != K1 or w3.shape[1] != N2 or (b2 is not None and b2.numel() != N2) or (b3 is not None and b3.numel() != N3):
+        raise ValueError("mlp2: shapes do not chain: x %s w2 %s w3 %s" % (tuple(x.shape), tuple(w2.shape), tuple(w3.shape)))
+    out = torch.empty((M, N3), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().reco_mlp2_f32(_p(x), x.stride(0) if M > 1 else K1, M, K1, _p(w2), _p(b2), N2, ACTS[act2], _p(w3), _p(b3), N3, ACTS[act3],
+                                       lo, hi, _p(out), N3, _stream(x.device)))
+    return out
+
+
 def transpose(x):
     """x.T as a new contiguous tensor (HIP kernel; used for the [K, N] weight layout of csr_linear)."""
     x = _f32(x, "input", 2)
@@ -148,6 +172,15 @@ def transpose(x):
     with torch.cuda.device(x.device):
         check(_lib.lib().reco_transpose_f32(_p(x), x.shape[0], x.shape[1], x.shape[1], _p(out), x.shape[0], _stream(x.device)))
     return out
+
+
+def csr_k_ranges(K, N):
+    """How many k ranges (XCD placement, CsrMatrix) pay for a [K, N] fp32 weight matrix: none while it is small enough to sit in
+    every XCD's 4-MB L2 next to the Infinity Cache (the Hybrid encoders' 3.8 / 6.2 MB: 1 range 0.080 / 0.114 ms against 0.106 /
+    0.153 ms with 8), four for the 12-MB AutoRec encoder (0.155 ms against 0.231 with one and 0.173 with eight), eight beyond.
+    Measured on an ML-1M-like matrix with Zipf item popularity (tools/csr_exp.py); more ranges also mean more, shorter segments."""
+    nbytes = int(K) * int(N) * 4
+    return 1 if nbytes <= (8 << 20) else (4 if nbytes <= (16 << 20) else 8)
 
 
 class CsrMatrix:

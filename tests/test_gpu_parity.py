@@ -438,6 +438,37 @@ def test_linear_shapes_and_epilogues(tower_precision):
         assert (err <= 4e-7 * (scale + 1) + 1e-6).all(), (M, N, K, "bias_per_row")
 
 
+def test_two_narrow_layers_in_one_launch_equal_two_linear_calls_bit_for_bit():
+    """reco_mlp2_f32 (the Hybrid encoders' 256 -> 128 -> 64 and decoders' 64 -> 128 -> 256, evaluate_hybridautorecncf_rating.py:78-106)
+    against two reco_linear_f32 calls: same bits, every row-count class around the 32-row tile, strided input rows, no biases,
+    other activations; the oracle's fp64 layers within the fp32 gate; unsupported widths are refused."""
+    from recommender_amd import ops
+    rng = np.random.default_rng(17)
+    for M, K1, N2, N3, act3 in ((1, 256, 128, 64, None), (31, 256, 128, 64, None), (32, 64, 128, 256, "relu"), (33, 256, 128, 64, None),
+                                (6040, 256, 128, 64, None), (3706, 64, 128, 256, "relu"), (500, 8, 32, 32, "sigmoid"), (97, 512, 128, 1024, None)):
+        x = torch.from_numpy(rng.standard_normal((M, K1)).astype(np.float32)).cuda()
+        w2 = torch.from_numpy((rng.standard_normal((N2, K1)) / np.sqrt(K1)).astype(np.float32)).cuda()
+        w3 = torch.from_numpy((rng.standard_normal((N3, N2)) / np.sqrt(N2)).astype(np.float32)).cuda()
+        b2 = torch.from_numpy(rng.standard_normal(N2).astype(np.float32)).cuda(); b3 = torch.from_numpy(rng.standard_normal(N3).astype(np.float32)).cuda()
+        assert ops.mlp2_supported(K1, N2, N3)
+        got = ops.mlp2(x, w2, b2, w3, b3, "relu", act3)
+        want = ops.linear(ops.linear(x, w2, b2, "relu", precision="f32"), w3, b3, act3, precision="f32")
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (M, K1, N2, N3)
+        h = np.maximum(x.cpu().numpy().astype(np.float64) @ w2.cpu().numpy().astype(np.float64).T + b2.cpu().numpy(), 0)
+        o = h @ w3.cpu().numpy().astype(np.float64).T + b3.cpu().numpy()
+        o = np.maximum(o, 0) if act3 == "relu" else (1 / (1 + np.exp(-o)) if act3 == "sigmoid" else o)
+        assert_close(got.cpu().numpy(), o, atol=2e-6 * max(1.0, float(np.abs(o).max())), what="mlp2 vs fp64 %s" % ((M, K1, N2, N3),))
+    wide = torch.from_numpy(rng.standard_normal((70, 300)).astype(np.float32)).cuda()       # a column block of a wider buffer
+    xs = wide[:, 16:272]
+    w2 = torch.randn(128, 256, device="cuda") * 0.05; w3 = torch.randn(64, 128, device="cuda") * 0.05
+    got = ops.mlp2(xs, w2, None, w3, None)
+    want = ops.linear(ops.linear(xs.contiguous(), w2, None, "relu", precision="f32"), w3, None, None, precision="f32")
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    assert not ops.mlp2_supported(48, 40, 64) and not ops.mlp2_supported(3706, 256, 128)
+    with pytest.raises(ValueError):
+        ops.mlp2(torch.zeros(4, 48, device="cuda"), torch.zeros(40, 48, device="cuda"), None, torch.zeros(64, 40, device="cuda"), None)
+
+
 def test_linear_random_shape_sweep(tower_precision):
     """Seeded sweep over ragged shapes and alignments (K odd -> 4-byte loads, K even -> 8-byte, strided A / C views)."""
     from recommender_amd import ops
