@@ -203,6 +203,14 @@ typedef struct reco_tower_desc {
 int  reco_tower_create(const reco_tower_desc_t* desc, void* stream, reco_tower_t** out);
 void reco_tower_destroy(reco_tower_t* t);
 
+/* Debug aid, NO COUNTERPART IN THE REFERENCE.  The layer-1 scale s (Conventions) is fixed when the handle is created; a later
+ * in-place write to the MLP tables or the first-layer weights that no caller-side cache can see (torch: param.data, which moves no
+ * version counter) leaves the handle with stale projections AND, if values grew, with activations clamped at 1/s.  This call
+ * recomputes the bound over the tables' current contents (one pass over both MLP tables, a few small launches on `stream`) and
+ * sets *stale (device int32, never cleared here) to 1 when the handle's s no longer covers it -- rebuild the handle then.
+ * Handles without a stored scale (GMF-only, split mode, no tables) report nothing.  Calls on one handle must not overlap. */
+int reco_tower_check_scale(reco_tower_t* t, int32_t* stale, void* stream);
+
 /* Multi-GPU helper, NO COUNTERPART IN THE REFERENCE (which is single-device).  The persistent tile kernels of score_matrix /
  * score_topk launch one workgroup per CU and each takes 152 of the CU's 160 KB of LDS, so a kernel of another stream -- RCCL's
  * all-gather of the previous step's top-k lists (recommender_amd/dist.py) -- finds no CU until a tile launch ends.  With
@@ -284,6 +292,14 @@ int reco_tower_score_topk_rows(reco_tower_t* t, const float* u_gmf, const float*
                                const float* u_mlp, const float* i_mlp, int64_t U, int64_t N, int k,
                                const uint8_t* exclude, int64_t ld_ex, int32_t* out_ids, float* out_scores,
                                void* ws, size_t ws_bytes, void* stream);
+
+/* reco_tower_score_topk_rows with the ranking evaluation's seen-item rule (src/autorec/utils/helper.py:272,313 as used by the
+ * Hybrid evaluation, hybridautorecncf.ipynb cell 13): `seen` (nullable) is the float rating matrix itself, [U, N] with row stride
+ * ld_seen; an entry > 0 marks the item as seen (score*(1-seen) - seen*1e10) -- no mask tensor is built. */
+int reco_tower_score_topk_rows_seen(reco_tower_t* t, const float* u_gmf, const float* i_gmf,
+                                    const float* u_mlp, const float* i_mlp, int64_t U, int64_t N, int k,
+                                    const float* seen, int64_t ld_seen, int32_t* out_ids, float* out_scores,
+                                    void* ws, size_t ws_bytes, void* stream);
 
 /* The same call for callers that cannot allocate or bring a workspace (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Identical results to

@@ -55,6 +55,7 @@ _SIGNATURES = {
     "reco_tower_create": (c_int, [POINTER(TowerDesc), c_void_p, POINTER(c_void_p)]),
     "reco_tower_destroy": (None, [c_void_p]),
     "reco_tower_set_reserved_cus": (c_int, [c_void_p, c_int]),
+    "reco_tower_check_scale": (c_int, [c_void_p, c_void_p, c_void_p]),
     "reco_tower_score_pairs": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "reco_tower_rows_workspace_bytes": (c_size_t, [c_int64]),
     "reco_tower_rows_workspace_bytes_for": (c_size_t, [c_void_p, c_int, c_int64]),
@@ -70,6 +71,8 @@ _SIGNATURES = {
                                              c_void_p, c_size_t, c_void_p]),
     "reco_tower_score_topk_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
                                            c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "reco_tower_score_topk_rows_seen": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
+                                                c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "reco_noalloc_scratch_bytes": (c_size_t, []),
     "reco_tower_topk_fused_workspace_bytes": (c_size_t, [c_void_p, c_int64, c_int64, c_int]),
     "reco_tower_score_topk_fused": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int,

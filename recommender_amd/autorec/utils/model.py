@@ -19,8 +19,16 @@ _dev_cache = weakref.WeakKeyDictionary()
 _csr_cache = weakref.WeakKeyDictionary()         # model -> (key of the attached rating matrix, ops.CsrMatrix of the encoder's batch)
 
 
-def _matrix_key(t):
-    return (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
+class _Attached:
+    """A rating matrix whose CSR form is kept: the entry HOLDS the tensor that was handed in and is matched by identity + version
+    counter.  (Keyed on data_ptr alone, a freed matrix's address could be handed by the caching allocator to the next same-shaped
+    matrix, whose fresh version counter 0 would match too: the encoder would silently run on the old matrix's CSR.)"""
+
+    def __init__(self, source, csr):
+        self.source, self.version, self.csr = source, source._version, csr
+
+    def matches(self, t):
+        return t is self.source and t._version == self.version
 
 
 class AutoRec(nn.Module):
@@ -61,12 +69,14 @@ class AutoRec(nn.Module):
         m = train_matrix.to(device=device, dtype=torch.float32).contiguous()
         k_dim = m.shape[0] if self.item_based else m.shape[1]
         csr = ops.CsrMatrix.from_dense(m, transpose=self.item_based, k_ranges=ops.csr_k_ranges(k_dim, self.num_hidden_units))
-        _csr_cache[self] = (_matrix_key(m), csr)
+        # matched later against the tensor the CALLER holds (a CPU or non-fp32 matrix was copied above: the copy dies here)
+        _csr_cache[self] = _Attached(train_matrix, csr)
         return csr
 
-    def _attached(self, m):
+    def _attached(self, given):
+        """The CSR form of `given` if that very tensor (unchanged since) was attached, else None."""
         hit = _csr_cache.get(self)
-        return hit[1] if hit is not None and hit[0] == _matrix_key(m) else None
+        return hit.csr if hit is not None and hit.matches(given) else None
 
     def _encoder_t(self, device):
         """encoder weight as [n_in, hidden] (the sparse kernel reads one contiguous row per observed entry), per weight version"""
@@ -75,10 +85,11 @@ class AutoRec(nn.Module):
             extra["WeT"] = ops.transpose(we)
         return extra["WeT"]
 
-    def _hidden_of(self, m, device):
-        """H = sigmoid(encoder(batch)) [items, hidden] for the item-based model and the [users, items] matrix m."""
+    def _hidden_of(self, m, device, given=None):
+        """H = sigmoid(encoder(batch)) [items, hidden] for the item-based model and the [users, items] matrix m (`given`: the
+        caller's tensor m was made from, for the attach_ratings match)."""
         we, be, wd, bd = self._weights(device)[1]
-        csr = self._attached(m)
+        csr = self._attached(m if given is None else given)
         if csr is not None:
             return ops.csr_linear(csr, self._encoder_t(device), be, act="sigmoid")
         return ops.linear(m, we, be, act="sigmoid", x_transposed=True)
@@ -112,7 +123,7 @@ class AutoRec(nn.Module):
         device = self._device_of(train_matrix)
         m = train_matrix.to(device=device, dtype=torch.float32).contiguous()
         if not self.item_based:
-            csr = self._attached(m)
+            csr = self._attached(train_matrix)
             if csr is None:
                 return self.reconstruct(m, clamp)
             we, be, wd, bd = self._weights(device)[1]
@@ -123,7 +134,7 @@ class AutoRec(nn.Module):
         # observed entries), and the decoder is run with its operands swapped, R_hat^T[u, i] = Wd[u, :] . H[i, :] + bd[u],
         # which lands directly in [users, items]
         we, be, wd, bd = self._weights(device)[1]
-        h = self._hidden_of(m, device)
+        h = self._hidden_of(m, device, train_matrix)
         act = (None, 0.0, 0.0) if clamp is None else ("clamp", float(clamp[0]), float(clamp[1]))
         # rows padded to whole 128-byte lines (3706 -> 3712 floats): aligned stores in the GEMM epilogue, float4 reads in the
         # top-k scan; the result is the [users, items] view of that buffer
@@ -138,7 +149,7 @@ class AutoRec(nn.Module):
         """
         device = self._device_of(train_matrix)
         m = train_matrix.to(device=device, dtype=torch.float32).contiguous()
-        pred = self.reconstruct_all(m, clamp)
+        pred = self.reconstruct_all(train_matrix, clamp)
         # the seen mask (train > 0, helper.py:272) is read off the rating matrix inside the select and the user subset is an
         # index list handed to the kernel: no mask tensor, no gathered copies
         return ops.topk_rows_seen(pred, k, m if mask_seen else None, users)
@@ -151,7 +162,7 @@ class AutoRec(nn.Module):
         device = self._device_of(train_matrix)
         sig, (we, be, wd, bd), extra = self._weights(device)
         x = train_matrix.to(device=device, dtype=torch.float32).contiguous()
-        extra["H"] = self._hidden_of(x, device)
+        extra["H"] = self._hidden_of(x, device, train_matrix)
         return extra["H"]
 
     def predict_user(self, user_id, item_ids=None, clamp=(1.0, 5.0)):

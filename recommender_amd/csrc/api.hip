@@ -18,6 +18,7 @@ int tower_launch_tile(int G, int has_l3, const float* img, const float* P, const
                       unsigned int* next_tile, const float* l1, int reserve_cus, hipStream_t s);
 int tower_launch_l1scale(const float* W1, const float* b1, int dm, const float* u_rows, int64_t u_elems,
                          const float* i_rows, int64_t i_elems, unsigned int* scratch, float* out, hipStream_t s);
+int tower_launch_scale_compare(const float* stored, const float* fresh, int32_t* stale, hipStream_t s);
 int tower_launch_pairs(int G, int has_l3, const float* img, const float* P, const float* Q,
                        const float* EUg, const float* EIg, const int64_t* user, const int64_t* item,
                        int64_t n_users, int64_t n_items, int64_t B, float* out, float bp, int act,
@@ -260,7 +261,7 @@ struct reco_tower {
 // Layer-1 scale words {s, 1/s} (tower_shared.h).  Inside a 256-byte block: floats at words kL1Word, kL1Word + 1, two scratch
 // words for the maxima behind them.  The handle owns such a block when it has tables; calls over row blocks handed in per call
 // compute theirs into the head of the call workspace (word 0 of that head is the tile work-queue counter).
-static const int kL1Word = 16, kL1ScratchWord = 20;
+static const int kL1Word = 16, kL1ScratchWord = 20, kL1CheckScratchWord = 24, kL1CheckWord = 28;
 
 static int tower_project(const reco_tower* t, const float* u_rows, const int64_t* u_idx, int64_t u_limit, int64_t U,
                          const float* i_rows, const int64_t* i_idx, int64_t i_limit, int64_t N,
@@ -395,6 +396,24 @@ extern "C" int reco_tower_create(const reco_tower_desc_t* d, void* stream, reco_
     if (rc) { reco_tower_destroy(t); return rc; }
     *out = t;
     return RECO_OK;
+}
+
+// Debug aid for the one way a handle can go wrong SILENTLY: the exact kernels clamp layer 1 at 1/s, s fixed at creation from a bound
+// over the tables; a write through param.data (no version counter moves, so no caller-side cache notices) that makes the embeddings
+// larger would saturate activations instead of merely using stale projections.  Recomputes the bound over the tables' CURRENT
+// contents (one pass over the MLP tables) and raises *stale when the handle's scale no longer covers it.
+extern "C" int reco_tower_check_scale(reco_tower_t* t, int32_t* stale, void* stream)
+{
+    RECO_REQUIRE(t && stale, "check_scale: null argument");
+    if (int rc_dev = check_device(t, "check_scale")) return rc_dev;
+    if (!t->l1) return RECO_OK;                 // GMF-only, split mode, or a handle without tables: nothing is clamped against a stored scale
+    hipStream_t s = (hipStream_t)stream;
+    const reco_tower_desc_t& d = t->d;
+    unsigned int* blk = reinterpret_cast<unsigned int*>(t->l1);
+    float* fresh = reinterpret_cast<float*>(blk + kL1CheckWord);
+    if (int rc = tower_launch_l1scale(d.W[0], d.b[0], d.dm, d.user_mlp, d.n_users * d.dm, d.item_mlp, d.n_items * d.dm,
+                                      blk + kL1CheckScratchWord, fresh, s)) return rc;
+    return tower_launch_scale_compare(t->l1 + 0, fresh, stale, s);
 }
 
 extern "C" int reco_tower_set_reserved_cus(reco_tower_t* t, int cus)
@@ -689,8 +708,10 @@ static int score_topk_fused(reco_tower_t* t, const int64_t* users, int64_t user_
 static int score_topk_impl(reco_tower_t* t, const int64_t* users, int64_t user_base, int64_t U,
                            const int64_t* cands, int64_t N, int k, const uint8_t* exclude, int64_t ld_ex,
                            int32_t* out_ids, float* out_scores, int32_t* oob, void* ws, size_t ws_bytes, hipStream_t s,
-                           const char* who)
+                           const char* who, const float* seen = nullptr, int64_t ld_seen = 0)
 {
+    RECO_REQUIRE(!seen || ld_seen >= N, "%s: ld_seen smaller than N", who);
+    RECO_REQUIRE(!(seen && exclude), "%s: give the seen items as a byte mask or as the rating matrix, not both", who);
     RECO_REQUIRE(out_ids && out_scores, "%s: null output", who);
     RECO_REQUIRE(k >= 1 && k <= 128, "%s: k must be in [1,128], got %d", who, k);
     RECO_REQUIRE(N >= k, "%s: k=%d exceeds the number of candidates %lld", who, k, (long long)N);
@@ -698,7 +719,7 @@ static int score_topk_impl(reco_tower_t* t, const int64_t* users, int64_t user_b
     int rc = check_ranges(t, users, user_base, U, cands, N, who);
     if (rc) return rc;
 
-    if (fused_topk_preferred(t, exclude, U, N))
+    if (!seen && fused_topk_preferred(t, exclude, U, N))
         return score_topk_fused(t, users, user_base, U, cands, N, k, out_ids, out_scores, oob, ws, ws_bytes, s, who);
 
     // largest user chunk the workspace admits
@@ -732,8 +753,8 @@ static int score_topk_impl(reco_tower_t* t, const int64_t* users, int64_t user_b
         const int64_t n = U - c0 < Uc ? U - c0 : Uc;
         rc = score_matrix_impl(t, users ? users + c0 : nullptr, user_base + c0, n, cands, N, Q, l1, scores, ldN, P, Q, queue, oob, s);
         if (rc) return rc;
-        rc = launch_topk_rows(scores, n, N, ldN, k, exclude ? exclude + c0 * ld_ex : nullptr, ld_ex, out_ids + c0 * k,
-                              out_scores + c0 * k, tws, tws_bytes, s);
+        rc = launch_topk_rows_ex(scores, n, N, ldN, k, exclude ? exclude + c0 * ld_ex : nullptr, ld_ex, seen ? seen + c0 * ld_seen : nullptr,
+                                 ld_seen, nullptr, n, nullptr, out_ids + c0 * k, out_scores + c0 * k, tws, tws_bytes, s);
         if (rc) return rc;
     }
     return RECO_OK;
@@ -809,6 +830,19 @@ extern "C" int reco_tower_score_topk_rows(reco_tower_t* t, const float* u_gmf, c
     if (int rc = rows_view(t, u_gmf, i_gmf, u_mlp, i_mlp, U, N, &v, "score_topk_rows")) return rc;
     if (U <= 0) return RECO_OK;
     return reco_tower_score_topk(&v, nullptr, 0, U, nullptr, N, k, exclude, ld_ex, out_ids, out_scores, nullptr, ws, ws_bytes, stream);
+}
+
+// the ranking evaluation's form: seen items are read off the float rating matrix itself (entry > 0), as reco_topk_rows_seen does
+extern "C" int reco_tower_score_topk_rows_seen(reco_tower_t* t, const float* u_gmf, const float* i_gmf,
+                                               const float* u_mlp, const float* i_mlp, int64_t U, int64_t N, int k,
+                                               const float* seen, int64_t ld_seen, int32_t* out_ids, float* out_scores,
+                                               void* ws, size_t ws_bytes, void* stream)
+{
+    reco_tower v;
+    if (int rc = rows_view(t, u_gmf, i_gmf, u_mlp, i_mlp, U, N, &v, "score_topk_rows_seen")) return rc;
+    if (U <= 0) return RECO_OK;
+    return score_topk_impl(&v, nullptr, 0, U, nullptr, N, k, nullptr, 0, out_ids, out_scores, nullptr, ws, ws_bytes, (hipStream_t)stream,
+                           "score_topk_rows_seen", seen, ld_seen);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -905,6 +905,12 @@ __global__ __launch_bounds__(H1) void l1scale_kernel(const float* __restrict__ W
     }
 }
 
+// *stale = 1 when the scale the tables need NOW (fresh) is smaller than the one the handle was built with (stored)
+__global__ void scale_compare_kernel(const float* stored, const float* fresh, int32_t* stale)
+{
+    if (threadIdx.x == 0 && fresh[0] < stored[0]) *stale = 1;
+}
+
 template <int G, bool L3>
 int launch_tile_t(const TileArgs& a, hipStream_t s)
 {
@@ -1090,6 +1096,13 @@ int tower_launch_l1scale(const float* W1, const float* b1, int dm, const float* 
         RECO_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(l1scale_kernel, dim3(1), dim3(H1), 0, s, W1, b1, dm, scratch, out);
+    RECO_CHECK_LAUNCH();
+    return RECO_OK;
+}
+
+int tower_launch_scale_compare(const float* stored, const float* fresh, int32_t* stale, hipStream_t s)
+{
+    hipLaunchKernelGGL(scale_compare_kernel, dim3(1), dim3(64), 0, s, stored, fresh, stale);
     RECO_CHECK_LAUNCH();
     return RECO_OK;
 }

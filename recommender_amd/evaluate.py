@@ -57,6 +57,6 @@ def hybrid_ranking_metrics(model, train_matrix, test_matrix, top_k=10):
     ops.require_gpu()
     p = next(model.parameters())
     device = p.device if p.is_cuda else torch.device("cuda", torch.cuda.current_device())
-    train = torch.as_tensor(np.asarray(train_matrix, np.float32)).to(device)      # one upload; the seen mask is formed on the device
-    ids, _ = model.score_all(train, k=top_k, exclude=train > 0)
+    train = torch.as_tensor(np.asarray(train_matrix, np.float32)).to(device)      # one upload; the select reads the seen items off it
+    ids, _ = model.score_all(train, k=top_k, mask_seen=True)
     return _multi_gt_metrics(ids.cpu().numpy(), np.asarray(test_matrix))

@@ -15,6 +15,8 @@ a module-level WeakKeyDictionary and is rebuilt whenever a parameter changes.
 """
 import weakref
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -112,7 +114,11 @@ class NCF(nn.Module):
         sig = (str(device), self._rating_epilogue(), ops.tower_precision()) + tuple((p.data_ptr(), p._version, str(p.device)) for p in flat)
         hit = _cache.get(self)
         if hit is not None and hit[0] == sig:
-            return hit[1]
+            # RECO_CHECK_STALE=1 (debug): a write through param.data moves no version counter, so `sig` cannot see it; the handle
+            # would go on with stale projections and -- if the embeddings grew -- with layer-1 activations clamped at the old
+            # scale.  The check costs a pass over the MLP tables and a sync per call: the handle is rebuilt when it fires.
+            if not (os.environ.get("RECO_CHECK_STALE") == "1" and isinstance(hit[1], ops.Tower) and hit[1].scale_is_stale()):
+                return hit[1]
 
         def dev(p):
             return p.detach().to(device=device, dtype=torch.float32)

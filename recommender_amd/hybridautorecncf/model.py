@@ -19,7 +19,7 @@ from .. import ops
 
 _tower_cache = weakref.WeakKeyDictionary()
 _weight_cache = weakref.WeakKeyDictionary()      # AutoEncoder -> {id(Sequential): (signature, [(weight, bias) on device])}
-_csr_cache = weakref.WeakKeyDictionary()         # HybridAutoRecNCF -> (key of the attached rating matrix, (CSR of R, CSR of R^T))
+_csr_cache = weakref.WeakKeyDictionary()         # HybridAutoRecNCF -> (attached tensor, its version, (CSR of R, CSR of R^T))
 
 
 def _f32_on(t, device):
@@ -166,7 +166,7 @@ class NCF(nn.Module):
         out = self._tower(device).score_rows(zu, zi, zu, zi)
         return out if out.device == src else out.to(src)
 
-    def score_matrix(self, zu, zi, k=None, exclude=None):
+    def score_matrix(self, zu, zi, k=None, exclude=None, seen=None):
         """pred[u, i] for every (row of zu, row of zi) -- the full-catalog form of forward -- or, with k, the per-user top-k
         (ids = row numbers of zi).  Runs on the cached head (weights packed once, keyed on parameter versions); the latents are
         handed to the kernels per call, so nothing is allocated besides the outputs and nothing synchronises."""
@@ -176,7 +176,7 @@ class NCF(nn.Module):
         tower = self._tower(device)
         if k is None:
             return tower.score_matrix_rows(zu, zi, zu, zi)
-        return tower.score_topk_rows(zu, zi, zu, zi, k, exclude)
+        return tower.score_topk_rows(zu, zi, zu, zi, k, exclude, seen=seen)
 
 
 class HybridAutoRecNCF(nn.Module):
@@ -205,19 +205,23 @@ class HybridAutoRecNCF(nn.Module):
         wide_i = next(m for m in self.item_autorec.encoder if isinstance(m, nn.Linear)).out_features
         pair = (ops.CsrMatrix.from_dense(R, k_ranges=ops.csr_k_ranges(R.shape[1], wide_u)),
                 ops.CsrMatrix.from_dense(R, transpose=True, k_ranges=ops.csr_k_ranges(R.shape[0], wide_i)))
-        _csr_cache[self] = ((R.data_ptr(), R._version, tuple(R.shape), str(R.device)), pair)
+        # the entry holds the caller's tensor and is matched by identity + version counter: an address alone can be recycled by the
+        # caching allocator for the next same-shaped matrix (whose version counter starts at 0 again)
+        _csr_cache[self] = (rating_matrix, rating_matrix._version, pair)
         return pair
 
-    def score_all(self, rating_matrix, k=None, exclude=None):
-        """Full-catalog joint scoring (cfg4): pred[users, items], or per-user top-k when k is given."""
+    def score_all(self, rating_matrix, k=None, exclude=None, mask_seen=False):
+        """Full-catalog joint scoring (cfg4): pred[users, items], or per-user top-k when k is given.
+        mask_seen=True (with k): items the user rated (rating_matrix > 0) are pushed to -1e10 before the select, read straight off
+        the rating matrix inside the kernel (helper.py:272,313) -- no mask tensor is formed."""
         ops.require_gpu()
         device = rating_matrix.device if rating_matrix.is_cuda else torch.device("cuda", torch.cuda.current_device())
         R = rating_matrix.to(device=device, dtype=torch.float32).contiguous()
         hit = _csr_cache.get(self)
-        if hit is not None and hit[0] == (R.data_ptr(), R._version, tuple(R.shape), str(R.device)):
-            zu = self.user_autorec.encode(hit[1][0])
-            zi = self.item_autorec.encode(hit[1][1])
+        if hit is not None and hit[0] is rating_matrix and hit[1] == rating_matrix._version:
+            zu = self.user_autorec.encode(hit[2][0])
+            zi = self.item_autorec.encode(hit[2][1])
         else:
             zu = self.user_autorec.encode(R)
             zi = self.item_autorec.encode(R, transposed=True)
-        return self.ncf.score_matrix(zu, zi, k, exclude)
+        return self.ncf.score_matrix(zu, zi, k, exclude, seen=R if (mask_seen and k is not None) else None)

@@ -532,6 +532,14 @@ class Tower:
         check(self._L.reco_tower_set_reserved_cus(self._h, int(cus)))
         self.reserved_cus = int(cus)
 
+    def scale_is_stale(self):
+        """True when the MLP tables / first-layer weights were changed in place since the handle was built in a way that its
+        layer-1 scale no longer covers (reco_tower_check_scale: one pass over the tables, one device-to-host sync)."""
+        flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self._L.reco_tower_check_scale(self._h, _p(flag), _stream(self.device)))
+        return bool(int(flag.item()))
+
     def _oob(self, check_ids):
         """Per-call counter of clamped ids (None: the caller validated its ids, nothing is counted and nothing synchronises)."""
         return torch.zeros(1, dtype=torch.int32, device=self.device) if check_ids else None
@@ -595,9 +603,27 @@ class Tower:
                                                        out.stride(0) if U > 1 else N, _p(ws), nbytes, _stream(self.device)))
         return out
 
-    def score_topk_rows(self, u_gmf, i_gmf, u_mlp, i_mlp, k=10, exclude=None, ws=None):
-        """(ids int32 [U,k] = row numbers of the item blocks, scores [U,k]): score_topk with per-call tables."""
+    def score_topk_rows(self, u_gmf, i_gmf, u_mlp, i_mlp, k=10, exclude=None, ws=None, seen=None):
+        """(ids int32 [U,k] = row numbers of the item blocks, scores [U,k]): score_topk with per-call tables.
+        seen: the float32 [U, N] rating matrix itself (entry > 0 = seen item, helper.py:272,313) instead of a byte mask."""
         tens, U, N = self._row_blocks(u_gmf, i_gmf, u_mlp, i_mlp)
+        if seen is not None:
+            if exclude is not None:
+                raise ValueError("give the seen items as a mask (exclude) or as the rating matrix (seen), not both")
+            if not (isinstance(seen, torch.Tensor) and seen.dim() == 2 and seen.is_cuda and seen.dtype == torch.float32
+                    and seen.stride(1) == 1 and seen.stride(0) >= seen.shape[1]):
+                seen = _f32(seen, "seen", 2)
+            if tuple(seen.shape) != (U, N) or seen.device != self.device:
+                raise ValueError("seen must be a float32 [%d, %d] matrix on %s, got %s" % (U, N, self.device, tuple(seen.shape)))
+            ids = torch.empty((U, k), dtype=torch.int32, device=self.device)
+            vals = torch.empty((U, k), dtype=torch.float32, device=self.device)
+            if ws is None:
+                ws = self.topk_workspace(U, N, k)
+            with torch.cuda.device(self.device):
+                check(self._L.reco_tower_score_topk_rows_seen(self._h, _p(tens[0]), _p(tens[1]), _p(tens[2]), _p(tens[3]), U, N, k, _p(seen),
+                                                              seen.stride(0) if U > 1 else N, _p(ids), _p(vals), _p(ws), ws.numel(),
+                                                              _stream(self.device)))
+            return ids, vals
         if exclude is not None:
             exclude = _mask(exclude, tens[2] if tens[2] is not None else tens[0])
             if tuple(exclude.shape) != (U, N):

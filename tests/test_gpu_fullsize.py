@@ -149,13 +149,19 @@ def test_cfg3_autorec_full_reconstruction_and_masked_topk(tower_precision):
     assert np.array_equal(vals_s.cpu().numpy(), oval_s) and np.array_equal(ids_s.cpu().numpy(), oid_s)
 
 
-def test_cfg4_hybrid_full_catalog(tower_precision):
+@pytest.mark.parametrize("matrix", ["ratings", "binary"])
+def test_cfg4_hybrid_full_catalog(tower_precision, matrix):
+    """cfg4 at full size on the same kind of X as cfg3 (ratings 1..5) and on the implicit 0/1 matrix the
+    hybridautorecncf notebook trains on."""
     from recommender_amd.hybridautorecncf.model import HybridAutoRecNCF
     torch.manual_seed(0)
     m = HybridAutoRecNCF(6040, 3706, 64, [128, 64], rating_output=False).eval()
     sd = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
     rng = np.random.default_rng(4)
-    R = (rng.random((6040, 3706)) < 0.045).astype(np.float32)
+    if matrix == "ratings":
+        R = ((rng.random((6040, 3706)) < 0.045) * rng.integers(1, 6, (6040, 3706))).astype(np.float32)      # cfg3's generator
+    else:
+        R = (rng.random((6040, 3706)) < 0.045).astype(np.float32)
     m = m.cuda()
     S = m.score_all(torch.from_numpy(R).cuda())                    # 22,384,240 pairs
     assert S.shape == (6040, 3706)
@@ -171,6 +177,9 @@ def test_cfg4_hybrid_full_catalog(tower_precision):
     ids, vals = m.score_all(torch.from_numpy(R).cuda(), k=10, exclude=torch.from_numpy(R > 0).cuda())
     oid, oval = O.topk_rows(O.mask_seen(S.cpu().numpy(), R > 0), 10)
     assert np.array_equal(ids.cpu().numpy(), oid) and np.array_equal(vals.cpu().numpy(), oval)
+    # the evaluator's form: seen items read off the rating matrix itself inside the select (no mask tensor)
+    ids_m, vals_m = m.score_all(torch.from_numpy(R).cuda(), k=10, mask_seen=True)
+    assert torch.equal(ids_m, ids) and torch.equal(vals_m, vals)
 
 
 def test_cfg5_slice_million_item_catalog_top100_user_chunking(tower_precision):

@@ -661,6 +661,37 @@ def test_scores_do_not_depend_on_the_layer1_scale(name):
         assert torch.equal(ia, ib) and torch.equal(va.view(torch.int32), vb.view(torch.int32))
 
 
+def test_a_param_data_write_never_silently_saturates_layer1(monkeypatch):
+    """A write through param.data moves no version counter, so the module's handle cache cannot see it (INTEGRATION section 1:
+    unsupported).  What must never happen silently is the NEW failure mode of the clamped layer 1: embeddings that grew beyond
+    the handle's scale s would be clipped at 1/s.  reco_tower_check_scale detects exactly that; with RECO_CHECK_STALE=1 the
+    module rebuilds its handle and returns the oracle's scores for the new weights."""
+    from recommender_amd.helpers import NCF
+    torch.manual_seed(8)
+    m = NCF(60, 90, 32, 3, 0.0, "NeuMF-end").eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "embed" in n:
+                p.mul_(30.0)
+    m = m.cuda()
+    dev = torch.device("cuda", 0)
+    u = torch.arange(60).repeat_interleave(90).cuda(); i = torch.arange(90).repeat(60).cuda()
+    before = m(u, i)
+    t = m._tower(dev)
+    assert not t.scale_is_stale()
+    m.embed_user_MLP.weight.data.mul_(0.5)                             # smaller values: stale projections, but nothing can saturate
+    assert not t.scale_is_stale()
+    m.embed_user_MLP.weight.data.mul_(2000.0)                          # larger: the old scale no longer covers p + q
+    assert m._tower(dev) is t and t.scale_is_stale()
+    monkeypatch.setenv("RECO_CHECK_STALE", "1")
+    after = m(u, i)
+    assert m._tower(dev) is not t                                      # rebuilt
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    want = O.ncf_forward(sd, u.cpu().numpy(), i.cpu().numpy())
+    assert_close(after.cpu().numpy(), want, atol=1e-6 * float(np.abs(want).max()), what="scores after the rebuild")
+    assert not torch.equal(before, after) and not m._tower(dev).scale_is_stale()
+
+
 @pytest.mark.parametrize("emb", [0.0, 1e-30, 1e-12, 1e12])
 @pytest.mark.parametrize("name", ["NeuMF-end", "MLP"])
 def test_degenerate_embedding_magnitudes_against_the_oracle(name, emb):
