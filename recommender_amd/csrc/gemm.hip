@@ -64,6 +64,7 @@ struct LinArgs {
     float* partial;        // [splits][M][N] raw accumulators when splits > 1
     int a_trans;           // A is stored [K, M] (row stride lda): C = act(A^T W^T + bias)
     int bias_rows;         // bias indexed by output row m instead of column n
+    int m_fast;              // tile order: 1 = walk the tile grid along m first (linear_kernel)
     const float* out_scale;  // nullable device word: every output is multiplied by it after bias + activation (the tower's layer-1
                              // projections are written pre-scaled by a power of two, tower_shared.h layer1_scale)
 };
@@ -144,9 +145,19 @@ __global__ __launch_bounds__(256, DMAT ? (ONE ? 4 : 2) : 1) void linear_kernel(L
     const int i = lane & 31, h = lane >> 5;
 
     const int64_t tiles_n = (a.N + BN - 1) / BN;
-    const int64_t tiles = tiles_n * ((a.M + BM - 1) / BM);
-    const int64_t tile = blockIdx.x % tiles;
+    const int64_t tiles_m = (a.M + BM - 1) / BM;
+    const int64_t tiles = tiles_n * tiles_m;
     const int split = (int)(blockIdx.x / tiles);
+    // Which output tile this workgroup computes.  Consecutive workgroups go to the 8 XCDs round-robin (speed only, never
+    // correctness) and every XCD has its own 4-MB L2.  Walking the tile grid along a dimension whose tile count is a multiple of
+    // 8 therefore gives XCD x every eighth operand slab of that dimension -- the same few slabs for the whole launch, L2-resident
+    // -- while the other operand's slab is shared by all eight at the same time.  The launcher picks that dimension as the fast
+    // one (m_fast).  AutoRec decoder, 48 x 29 tiles of 128 x 128 (operands swapped so that R_hat lands in [users, items]):
+    // n fastest 0.244 ms, m fastest 0.231; the unswapped 29 x 48 form: n fastest 0.230, m fastest 0.243.  Contiguous tile ranges
+    // per XCD and Triton-style grouped orders (groups of 2-8 tile rows / columns, with and without the per-XCD ranges) were
+    // measured too: each helps one orientation by the same 5 % and costs the other 13-19 %.
+    int64_t tile = blockIdx.x % tiles;
+    if (a.m_fast) tile = (tile % tiles_m) * tiles_n + tile / tiles_m;
     const int64_t m0 = (tile / tiles_n) * BM;
     const int64_t n0 = (tile % tiles_n) * BN;
     const int64_t kb = split * a.k_per_split;                                   // this block's K slice [kb, ke)
@@ -392,22 +403,40 @@ __global__ __launch_bounds__(256, DMAT ? (ONE ? 4 : 2) : 1) void linear_kernel(L
 
     // epilogue: D[row = (r&3) + 8 (r>>2) + 4 h][col = lane & 31]
     const float osc = a.out_scale ? a.out_scale[0] : 1.f;
+    const bool brows = a.bias && a.bias_rows, bcols = a.bias && !a.bias_rows;
+    float bvn[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int64_t n = n0 + wn * (BN / 2) + tn * 32 + i;
-        if (n >= a.N) continue;
-        const float bv = (a.bias && !a.bias_rows) ? a.bias[n] : 0.f;
+        bvn[tn] = (bcols && n < a.N) ? a.bias[n] : 0.f;
+    }
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
+    for (int tm = 0; tm < TM; ++tm) {
+        // per-row bias (the AutoRec decoder run with swapped operands): this lane's rows four at a time, not once per element
+        // (loaded inside the element loop it cost the swapped decoder 13 %: 0.265 against 0.235 ms)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m >= a.M) continue;
+        for (int rq = 0; rq < 4; ++rq) {
+            float brow[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int64_t m = m0 + wm * (BM / 2) + tm * 32 + jj + 8 * rq + 4 * h;
+                brow[jj] = (brows && m < a.M) ? a.bias[m] : 0.f;
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int64_t n = n0 + wn * (BN / 2) + tn * 32 + i;
+                if (n >= a.N) continue;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int r = 4 * rq + jj;
+                    const int64_t m = m0 + wm * (BM / 2) + tm * 32 + jj + 8 * rq + 4 * h;
+                    if (m >= a.M) continue;
 #ifdef RECO_ABL_GEMM_NO_STORE      // timing-only ablation: the stores stay in the code but never execute
-                if (acc[tm][tn][r] != 12345.678f) continue;
+                    if (acc[tm][tn][r] != 12345.678f) continue;
 #endif
-                if (a.splits > 1) a.partial[((int64_t)split * a.M + m) * a.N + n] = acc[tm][tn][r];
-                else a.C[m * a.ldc + n] = apply_act(acc[tm][tn][r] + ((a.bias && a.bias_rows) ? a.bias[m] : bv), a.act, a.lo, a.hi) * osc;
+                    if (a.splits > 1) a.partial[((int64_t)split * a.M + m) * a.N + n] = acc[tm][tn][r];
+                    else a.C[m * a.ldc + n] = apply_act(acc[tm][tn][r] + (brows ? brow[jj] : bvn[tn]), a.act, a.lo, a.hi) * osc;
+                }
             }
         }
     }
@@ -529,7 +558,7 @@ int launch_linear_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_
     RECO_REQUIRE(lda >= (at ? M : K) && ldw >= K && ldc >= N, "linear: leading dimension smaller than the row");
     RECO_REQUIRE(!(at && a_rows), "linear: row gather and transposed A cannot be combined");
     LinArgs a{A, lda, a_rows, a_rows ? a_row_limit : M, M, W, ldw, bias, N, K, act, lo, hi, C, ldc, oob, 1, K, nullptr,
-              at ? 1 : 0, (flags & RECO_LINEAR_BIAS_PER_ROW) ? 1 : 0, out_scale};
+              at ? 1 : 0, (flags & RECO_LINEAR_BIAS_PER_ROW) ? 1 : 0, 0, out_scale};
     int vec = 1;
     const bool a4 = at || (lda % 4 == 0 && (uintptr_t)A % 16 == 0), a2 = at || (lda % 2 == 0 && (uintptr_t)A % 8 == 0);
     if (a4 && ldw % 4 == 0 && (uintptr_t)W % 16 == 0) vec = 4;
@@ -553,6 +582,11 @@ int launch_linear_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_
             a.partial = static_cast<float*>(ws);
             if (a.splits <= 1) { a.splits = 1; a.k_per_split = K; a.partial = nullptr; }
         }
+    }
+    {   // fast dimension of the tile order: the one whose tile count is a multiple of 8 (linear_kernel), else the longer one
+        const int64_t tm = ceil_div64(M, bm), tn = ceil_div64(N, bn);
+        const bool gm = tm % 8 == 0, gn = tn % 8 == 0;
+        a.m_fast = (gm != gn) ? (gm ? 1 : 0) : (tm > tn ? 1 : 0);
     }
     if (flags & RECO_LINEAR_SPLIT_BF16X3) return launch_tile<true>(a, bm, bn, vec, s);
     return launch_tile<false>(a, bm, bn, vec, s);

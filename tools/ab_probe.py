@@ -77,6 +77,15 @@ def main(which):
         measure("autorec recommend_topk dense", lambda: a.recommend_topk(R, 10))
         a.attach_ratings(R)
         measure("autorec recommend_topk csr", lambda: a.recommend_topk(R, 10))
+    if "dec" in which:
+        h = torch.randn(3706, 500, device=dev); wd = torch.randn(6040, 500, device=dev) * 0.05; bd = torch.randn(6040, device=dev)
+        buf = torch.empty((6040, 3712), device=dev)
+        measure("decoder swapped (M=6040 N=3706, bias per row, ldc 3712)", lambda: ops.linear(wd, h, bd, "clamp", 1.0, 5.0, bias_per_row=True, out=buf[:, :3706]))
+        measure("decoder plain (M=3706 N=6040)", lambda: ops.linear(h, wd, bd, "clamp", 1.0, 5.0))
+        x = torch.randn(3706, 6040, device=dev); we = torch.randn(500, 6040, device=dev) * 0.02; be = torch.randn(500, device=dev)
+        measure("encoder dense (M=3706 N=500 K=6040)", lambda: ops.linear(x, we, be, "sigmoid"))
+        xt = x.t().contiguous()
+        measure("encoder dense, A transposed", lambda: ops.linear(xt, we, be, "sigmoid", x_transposed=True))
     if "topk" in which:
         s = torch.randn(115056, 100, device=dev)
         measure("topk 115056x100 k=10", lambda: ops.topk_rows(s, 10))
