@@ -112,8 +112,10 @@ int reco_linear_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_t 
  *   C[m, :] = act( sum over the nonzeros (k, x) of row m in ascending k of  x * Wt[k, :]  + bias )
  * row_ptr [M+1] int64, col [nnz] int32 (ascending within a row; values outside [0, K) are clamped, never read out of range),
  * val [nnz]; Wt = W^T [K, N] row-major with row stride ldwt (reco_transpose_f32 of the nn.Linear weight, once per weight
- * version).  Zeros contribute nothing to an fp32 sum, so the result is the dense layer's k-ordered fmaf chain without its
- * zero terms.  The segment table cuts the rows into pieces of at most 256 consecutive nonzeros, one workgroup each:
+ * version).  Zeros contribute nothing to an fp32 sum: a row that is ONE segment is the dense layer's k-ordered fmaf chain without
+ * its zero terms, bit for bit; a row cut into several segments sums each on its own and adds the partial sums in segment order
+ * (plain adds: another rounding sequence, same fp32 gate).  The segment table cuts the rows into pieces of at most 256
+ * consecutive nonzeros, one wave each:
  *   row_seg_ptr [M+1] int64   segments of row m are row_seg_ptr[m] .. row_seg_ptr[m+1]-1 (a row without nonzeros has none),
  *   seg_row [S] int32, seg_begin / seg_end [S] int64 (offsets into col / val);
  * a row with one segment is finished in place, the partial sums of the others are added in segment order by a second launch

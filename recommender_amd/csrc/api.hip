@@ -621,7 +621,7 @@ static size_t fused_partial_bytes(int64_t Uc, int v, int k) { return align_up((s
 
 static size_t fused_chunk_bytes(int G, int64_t Uc, int64_t N, int k)
 {
-    return kQueueBytes + proj_bytes(N) + proj_bytes(Uc) + tower_topk_counter_bytes(G, Uc) + fused_partial_bytes(Uc, fuse_visitors(G, Uc, N, k), k);
+    return kQueueBytes + proj_bytes(N) + proj_bytes(Uc) + tower_topk_counter_bytes(G, Uc) + fused_partial_bytes(Uc, fuse_visitors(G, Uc, N, k), k) + 256;
 }
 
 static int64_t fused_default_chunk(int64_t U, int k)
@@ -666,10 +666,16 @@ static int score_topk_fused(reco_tower_t* t, const int64_t* users, int64_t user_
                             const char* who)
 {
     const reco_tower_desc_t& d = t->d;
+    // Largest user chunk the workspace admits.  The number of partial lists per block is NOT monotone in the chunk size (few
+    // blocks ask for one list per CU, fuse_visitors), so the chunk is sized against the MINIMUM list count and the lists then
+    // take whatever room is left, up to what fuse_visitors asks for -- a bounded workspace (the 32 MiB no-alloc scratch) no
+    // longer skips feasible chunk sizes.
+    auto fixed_bytes = [&](int64_t uc) { return kQueueBytes + proj_bytes(N) + proj_bytes(uc) + tower_topk_counter_bytes(t->G, uc); };
+    auto min_bytes = [&](int64_t uc) { return fixed_bytes(uc) + fused_partial_bytes(uc, kFuseVisitorsMin, k) + 256; };
     int64_t Uc = fused_default_chunk(U, k);
-    while (Uc > 1 && fused_chunk_bytes(t->G, Uc, N, k) > ws_bytes) Uc = whole_blocks(Uc / 2);
-    if (!ws || fused_chunk_bytes(t->G, Uc, N, k) > ws_bytes) {
-        reco_set_error("%s: workspace too small (%zu bytes; one user needs %zu)", who, ws_bytes, fused_chunk_bytes(t->G, 1, N, k));
+    while (Uc > 1 && min_bytes(Uc) > ws_bytes) Uc = whole_blocks(Uc / 2);
+    if (!ws || min_bytes(Uc) > ws_bytes) {
+        reco_set_error("%s: workspace too small (%zu bytes; one user needs %zu)", who, ws_bytes, min_bytes(1));
         return RECO_ENOMEM;
     }
     char* w = static_cast<char*>(ws) + kQueueBytes;
@@ -677,7 +683,9 @@ static int score_topk_fused(reco_tower_t* t, const int64_t* users, int64_t user_
     float* P = reinterpret_cast<float*>(w); w += proj_bytes(Uc);
     unsigned int* counters = reinterpret_cast<unsigned int*>(w);
     const size_t counter_bytes = tower_topk_counter_bytes(t->G, Uc);       // whole chunks and the last, shorter one share this split
-    const int64_t list_room = Uc * fuse_visitors(t->G, Uc, N, k);                // partial lists the workspace was sized for
+    int64_t list_room = (int64_t)((ws_bytes - fixed_bytes(Uc) - 256) / ((size_t)k * sizeof(uint64_t)));   // partial lists that fit (their block is padded to 256 B)
+    if (list_room > Uc * fuse_visitors(t->G, Uc, N, k)) list_room = Uc * fuse_visitors(t->G, Uc, N, k);
+    if (list_room > Uc * (int64_t)kFuseVisitorsMax) list_room = Uc * (int64_t)kFuseVisitorsMax;
     unsigned long long* partial = reinterpret_cast<unsigned long long*>(w + counter_bytes);
     const bool cached_q = !cands && N == d.n_items && U <= kServingUsers && t->Q;     // as the unfused form below
     int rc = RECO_OK;
@@ -692,7 +700,7 @@ static int score_topk_fused(reco_tower_t* t, const int64_t* users, int64_t user_
         if ((rc = tower_project(t, urows, ul, d.n_users, n, nullptr, nullptr, 0, 0, P, nullptr, oob, l1, s))) return rc;
         // hand-out counters and partial lists start at zero (a list nobody wrote reads as empty)
         int v = fuse_visitors(t->G, n, N, k);                                    // a short last chunk may take more lists per block
-        if ((int64_t)v * n > list_room) v = (int)(list_room / n);
+        if ((int64_t)v * n > list_room) v = (int)(list_room / n);                // >= kFuseVisitorsMin: the chunk was sized for it
         RECO_CHECK_HIP(hipMemsetAsync(counters, 0, counter_bytes + fused_partial_bytes(n, v, k), s));
         {
             ProfScope prof(s, RECO_PROF_TOWER);

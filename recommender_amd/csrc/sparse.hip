@@ -7,7 +7,12 @@
 // A zero contributes exactly nothing to an fp32 sum, so only the observed entries are visited:
 //   C[m, :] = act( sum over the nonzeros (k, x) of row m, ascending k:  x * Wt[k, :]  + bias )
 // with Wt = W^T stored [K, N] row-major (one transposed copy per weight version, reco_transpose_f32), i.e. one contiguous
-// N-float row per nonzero.  The sum is an fmaf chain in ascending k -- the dense kernel's chain with the zero terms left out.
+// N-float row per nonzero.  Summation order: inside a SEGMENT (below) an fmaf chain in ascending k starting from 0; a row that is
+// ONE segment is therefore the dense kernel's k-ordered chain with the zero terms left out, bit for bit.  A row cut into several
+// segments (one per k range it has entries in, and one per 256 entries) sums each segment on its own and then adds the partial
+// sums in segment order with plain float adds -- a different rounding sequence, within the fp32 gate of the dense layer but not
+// bit-identical to it.  No reference fixture pins this path bit for bit; its parity tests compare against the dense layer with a
+// tolerance and reserve equality for single-segment rows.
 //
 // Work is cut into SEGMENTS: at most 256 consecutive nonzeros of one row whose k lie in ONE of eight k ranges (table built
 // once per matrix by the host side; the ranges hold equal shares of the nonzeros).  One 256-thread workgroup per segment and

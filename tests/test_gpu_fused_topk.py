@@ -66,7 +66,7 @@ def test_fused_ragged_shapes_lists_and_duplicates():
 
 def test_fused_few_users_long_catalog_many_workgroups_share_a_block():
     # 3 users x 40,000 items: ONE user block, 625 item tiles, 256 workgroups -> every workgroup joins that block with a partial
-    # list of its own (768 are provided), and the merge folds 768 lists per user, most of them empty.  16 users take the request
+    # list of its own (256 are provided: one per CU), and the merge folds 256 lists per user, most of them empty.  16 users take the request
     # path (the handle's cached item projections); 40 users are two blocks.
     m, t = _model(64, 40000, 5, scale=10.0)
     for U in (3, 16, 17, 40):
@@ -92,6 +92,31 @@ def test_fused_more_user_blocks_than_workgroups_and_chunked_workspace():
         t.score_topk(None, 50, ws=torch.empty(4096, dtype=torch.uint8, device="cuda"), fused=True)
 
 
+def test_fused_bounded_workspace_takes_the_largest_feasible_chunk():
+    """The number of partial lists a chunk asks for is not monotone in its size (fewer than 128 user blocks -> one list per CU):
+    a bounded workspace must still settle on the largest chunk that fits with the MINIMUM list count instead of halving past it
+    (ADVICE r2).  Counted through the measurement hook: one tile launch per chunk."""
+    import ctypes
+    from recommender_amd import _lib
+    L = _lib.lib()
+    m, t = _model(6000, 2048, 11)
+    k, U, N = 10, 6000, 2048
+    plain = t.score_topk(None, k)
+    ws_bytes = 6 << 20
+    small = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    _lib.check(L.reco_profile_enable_kinds(256, 1 << _lib.PROF_TOWER))
+    chunked = t.score_topk(None, k, ws=small, fused=True)
+    torch.cuda.synchronize()
+    ms = (ctypes.c_float * 256)(); n = ctypes.c_int(0)
+    _lib.check(L.reco_profile_collect(ms, 256, ctypes.byref(n)))
+    _lib.check(L.reco_profile_enable(0))
+    assert _same(chunked, plain)
+    per_user = 128 * 4 + 4 * k * 8 + 1                       # one projection row + the minimum of four partial lists
+    room = ws_bytes - N * 128 * 4 - 8192                     # minus the item projections and the queue / counter blocks
+    needed = -(-U * per_user // room)
+    assert needed <= n.value <= 2 * needed + 1, (n.value, needed)
+
+
 def test_fused_out_of_range_ids_are_counted_once():
     m, t = _model(100, 200, 8)
     with pytest.raises(IndexError):
@@ -113,7 +138,7 @@ def test_fused_is_refused_where_there_is_no_fused_kernel():
 
 
 def test_fused_hybrid_head_shape_with_tables():
-    """dg = dm = 64, two layers (the Hybrid head): 16 users per block, 512 threads.  The latents stand in as tables."""
+    """dg = dm = 64, two layers (the Hybrid head): 24 users per block, 768 threads, like the NeuMF shapes.  The latents stand in as tables."""
     import recommender_amd.hybridautorecncf.model as hm
     from recommender_amd import ops
     torch.manual_seed(11)
