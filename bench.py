@@ -470,6 +470,12 @@ def main_rank(args):
                 "note": "opt-in RECO_PREC_SPLIT_BF16X3 (not the headline): fp32 operands split exactly into three bf16 pieces, six cross "
                         "terms on v_mfma_f32_32x32x16_bf16, fp32 accumulate; passes the same parity tests as the exact mode"}
         if cfg5 is not None:
+            if world == 1 and cfg5.get("roofline"):
+                t5, t5_src = measured_traffic("tower_tile_topk_kernel<32, true")
+                if t5 is not None:
+                    cfg5["roofline"].update({"traffic": t5, "traffic_source": t5_src,
+                                             "traffic_note": "HBM bytes per launch from separate rocprofv3 --pmc passes of this command, not live",
+                                             "traffic_algorithmic_bytes": args.cfg5_users_per_gpu * 100 * 8 + (10 ** 6) * (128 + 32) * 4})
             res["cfg5_top100"] = cfg5
         if kernels is not None:
             res.update(kernels)

@@ -27,6 +27,7 @@ import torch
 
 from recommender_amd import _lib, ops
 
+WARM_SECONDS = 0.08            # load before a section's timed steps (see timed())
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md
 MFMA_F32_PEAK = 157.3          # TFLOP/s dense fp32 MFMA
 NEUMF_EXEC, NEUMF_ALG = 20768, 86176
@@ -39,8 +40,15 @@ KIND_NAMES = {_lib.PROF_TOWER: "tower", _lib.PROF_GATHER: "gather", _lib.PROF_LI
 def timed(fn, steps, warmup, dev, launches_per_step_cap=24):
     """(wall ms per step, [(kind, mean kernel ms, launches)] by position within a step)."""
     L = _lib.lib()
-    for _ in range(warmup):
+    # warm-up by TIME as well as by count: the sections start after host-side set-up during which the GPU idles, and the device
+    # clock needs ~30 ms of load to settle again (the same effect bench.py's --precondition removes from the headline region);
+    # one rank only runs these sections, so a data-dependent step count cannot desynchronise a collective
+    t_warm, n_warm = time.perf_counter(), 0
+    while n_warm < warmup or time.perf_counter() - t_warm < WARM_SECONDS:
         fn()
+        n_warm += 1
+        if n_warm % 8 == 0:
+            torch.cuda.synchronize(dev)
     cap = steps * launches_per_step_cap
     torch.cuda.synchronize(dev)
     _lib.check(L.reco_profile_enable(cap))
