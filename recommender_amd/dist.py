@@ -17,10 +17,12 @@ With ONE rank the lists are already complete: no collective is issued at all.
 Ordering of the collective behind the kernels that produce its input ("the round-1 hang"):
 RCCL ("nccl") launches the collective as a kernel on its own stream behind an event recorded on the caller's stream, so
 it is stream-ordered by construction.  Any other backend (gloo: the CPU tests, and rehearsals where several ranks share
-one GPU) stages device tensors through host memory from a helper thread; issued asynchronously behind unfinished
-kernels, that staging never completed on a shared GPU (both ranks stuck in work.wait() for good).  For those backends
-the producer is therefore finished first (an event recorded behind the top-k kernel, waited for on the host) and
-work.wait() carries a timeout, so a stuck collective raises GatherTimeout instead of hanging the job.
+one GPU) only ever sees HOST tensors here: the packed lists are copied to the host behind the kernels that produce them (a
+synchronous copy on the compute stream), gathered there, and the result is copied back.  gloo's own handling of device tensors
+(staging through pinned memory from a helper thread on private streams) hung on a shared GPU -- in round 1 whenever the
+producing kernels were still enqueued, and in round 3 after some tens of back-to-back steps even with the producer finished
+first (8 warm-up steps passed, 48 did not).  work.wait() carries a timeout, so a stuck collective raises GatherTimeout
+instead of hanging the job.
 """
 import datetime
 import os
@@ -130,11 +132,17 @@ def all_gather_topk(ids, vals, counts=None, group=None):
         counts = [ids.shape[0]] * world
     mx = max(counts)
     buf = _pack(ids, vals, mx)
-    out = torch.empty((world * 2, mx, k), dtype=torch.int32, device=ids.device)    # concatenation along dim 0
     ordered = _stream_ordered(group)
-    if not ordered:
-        _finish_producer(buf)
-    _wait(dist.all_gather_into_tensor(out, buf, group=group, async_op=True), ordered)
+    if not ordered and buf.is_cuda:                 # host staging of our own (module docstring)
+        host = buf.cpu()                            # stream-ordered behind the producer, returns when the copy is done
+        out_host = torch.empty((world * 2, mx, k), dtype=torch.int32)
+        _wait(dist.all_gather_into_tensor(out_host, host, group=group, async_op=True), ordered)
+        out = out_host.to(ids.device)
+    else:
+        out = torch.empty((world * 2, mx, k), dtype=torch.int32, device=ids.device)    # concatenation along dim 0
+        if not ordered:
+            _finish_producer(buf)
+        _wait(dist.all_gather_into_tensor(out, buf, group=group, async_op=True), ordered)
     return _unpack(out.view(world, 2, mx, k), counts, k)
 
 
@@ -197,7 +205,12 @@ class TopkGather:
             if self.count < mx:
                 buf.zero_()
             gathered = torch.empty((self.world * 2, mx, k), dtype=torch.int32, device=self.device) if self.on else None
-            self.slots.append({"buf": buf, "ids": ids[:self.count], "vals": vals[:self.count], "gathered": gathered, "work": None})
+            # a backend that is not stream-ordered gathers on the host (module docstring): staging buffers per slot
+            staged = self.on and not self.ordered and self.device.type == "cuda"
+            host_in = torch.empty((2, mx, k), dtype=torch.int32).pin_memory() if staged else None
+            host_out = torch.empty((self.world * 2, mx, k), dtype=torch.int32).pin_memory() if staged else None
+            self.slots.append({"buf": buf, "ids": ids[:self.count], "vals": vals[:self.count], "gathered": gathered, "work": None,
+                               "host_in": host_in, "host_out": host_out})
         self.i = 0
         self.pending = None
 
@@ -206,6 +219,8 @@ class TopkGather:
             return slot["ids"], slot["vals"]
         work, slot["work"] = slot["work"], None
         _wait(work, self.ordered)
+        if slot["host_out"] is not None:
+            slot["gathered"].copy_(slot["host_out"])
         return _unpack(slot["gathered"].view(self.world, 2, -1, self.k), self.counts, self.k)
 
     def step(self):
@@ -214,9 +229,13 @@ class TopkGather:
         self.tower.score_topk((self.start, self.count), self.k, self.candidates, None, check_ids=False, ws=self.ws,
                               out=(slot["ids"], slot["vals"]))
         if self.on:
-            if not self.ordered:
-                _finish_producer(slot["buf"])
-            slot["work"] = dist.all_gather_into_tensor(slot["gathered"], slot["buf"], group=self.group, async_op=True)
+            if slot["host_in"] is not None:
+                slot["host_in"].copy_(slot["buf"])          # behind the top-k kernel on the compute stream; done when it returns
+                slot["work"] = dist.all_gather_into_tensor(slot["host_out"], slot["host_in"], group=self.group, async_op=True)
+            else:
+                if not self.ordered:
+                    _finish_producer(slot["buf"])
+                slot["work"] = dist.all_gather_into_tensor(slot["gathered"], slot["buf"], group=self.group, async_op=True)
         done = self._collect(self.pending) if self.pending is not None else None
         self.pending = slot
         return done
