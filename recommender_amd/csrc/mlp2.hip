@@ -7,7 +7,7 @@
 // Here a workgroup takes 32 rows of X: the rows are staged in LDS once, wave w computes output features [32 w, 32 w + 32) of
 // the first layer with the ROW on the MFMA column, ReLU'd results go to a second LDS tile, and the second layer runs out of
 // that tile -- the intermediate never leaves the CU.  Weights are read straight from global memory (L2-resident: 160 KB),
-// four k-quads ahead of their MFMAs.
+// sixteen k-quads ahead of their MFMAs.
 // Numerics: every output is the k-ordered fmaf chain of gemm.hip's linear_kernel without split-K (same MFMA, same k order
 // k = 8 q + 4 h + jj), so the results equal two reco_linear_f32 calls bit for bit.
 #include "reco_common.h"
