@@ -322,6 +322,7 @@ def main_rank(args):
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # before anything opens the HIP runtime (RCCL needs dmabuf IPC on this pool)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
