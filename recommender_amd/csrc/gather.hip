@@ -10,6 +10,18 @@
 // HBM-roofline measurement of the gather itself.
 #include "reco_common.h"
 
+// Loads in flight per thread x workgroups, same-box A/B on HBM-resident tables (tools/ab_run.sh; fused 4-table gather of 2^22 pairs /
+// gather_rows D = 128, ms):  4 x 4096 (round 2): 2.001 / 0.832    8 x 4096: 2.282 / 0.886    2 x 4096: 1.941 / 0.772    3 x 4096: 1.969 / 0.785
+//   1 x 4096: 1.821 / 0.772    1 x 8192: 1.859 / 0.789    1 x 3072: 2.046 / 0.822    1 x 1024: 2.497 / 0.839    **1 x 2048: 1.800 / 0.767**
+// One float4 per thread with every CU's 32 wave slots filled (8 workgroups of 256 per CU) beats deeper per-thread unrolling: the
+// unrolled loads of a thread lie a whole grid sweep apart and scatter the write stream over as many DRAM pages.
+#ifndef RECO_GATHER_UNROLL
+#define RECO_GATHER_UNROLL 1
+#endif
+#ifndef RECO_GATHER_BLOCKS
+#define RECO_GATHER_BLOCKS 2048
+#endif
+
 namespace {
 
 __device__ __forceinline__ int64_t clamp_row(int64_t id, int64_t n, int32_t* oob, bool count)
@@ -26,9 +38,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
                                                           const int64_t* __restrict__ idx, int64_t B,
                                                           float* __restrict__ out, int32_t* oob)
 {
-    // 4 independent float4 per thread in flight (ids first, then rows, then the streaming stores): with one load per
-    // thread the kernel is latency-bound well below the HBM rate
-    constexpr int UNROLL = 4;
+    // UNROLL independent float4 per thread in flight (ids first, then rows, then the streaming stores); see the sweep above
+    constexpr int UNROLL = RECO_GATHER_UNROLL;
     const int64_t total = B * dim4;
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x; t0 < total; t0 += stride * UNROLL) {
@@ -70,7 +81,7 @@ struct FusedArgs {
 template <bool POW2>
 __global__ __launch_bounds__(256) void neumf_gather_kernel(FusedArgs a, int sh_m, int sh_g)
 {
-    constexpr int UNROLL = 4;
+    constexpr int UNROLL = RECO_GATHER_UNROLL;
     const int64_t stride = (int64_t)gridDim.x * 256;
     if (a.mlp_in) {
         const int per_pair = 2 * a.m4;
@@ -131,7 +142,7 @@ static int log2_exact(int v)
 unsigned stream_grid(int64_t work_items)
 {
     const int64_t blocks = ceil_div64(work_items, 256);
-    return (unsigned)(blocks < 256 * 16 ? (blocks > 0 ? blocks : 1) : 256 * 16);
+    return (unsigned)(blocks < RECO_GATHER_BLOCKS ? (blocks > 0 ? blocks : 1) : RECO_GATHER_BLOCKS);
 }
 
 }  // namespace

@@ -77,6 +77,17 @@ def main(which):
         measure("autorec recommend_topk dense", lambda: a.recommend_topk(R, 10))
         a.attach_ratings(R)
         measure("autorec recommend_topk csr", lambda: a.recommend_topk(R, 10))
+    if "gather" in which:
+        U, I, B = 4_000_000, 1_000_000, 1 << 22
+        g = torch.Generator(device=dev).manual_seed(11)
+        eug, eig = torch.randn(U, 32, device=dev, generator=g), torch.randn(I, 32, device=dev, generator=g)
+        eum, eim = torch.randn(U, 128, device=dev, generator=g), torch.randn(I, 128, device=dev, generator=g)
+        uu = torch.randint(0, U, (B,), device=dev, generator=g); ii = torch.randint(0, I, (B,), device=dev, generator=g)
+        gp = torch.empty((B, 32), dtype=torch.float32, device=dev)
+        measure("neumf gather 4M pairs HBM tables", lambda: ops.neumf_gather(eug, eig, eum, eim, uu, ii, check_ids=False, gmf_out=gp), steps=10, warm=20)
+        measure("gather_rows D=128 4M rows", lambda: ops.gather_rows(eum, uu, check_ids=False), steps=10, warm=20)
+        del eug, eig, eum, eim, uu, ii, gp
+        torch.cuda.empty_cache()
     if "dec" in which:
         h = torch.randn(3706, 500, device=dev); wd = torch.randn(6040, 500, device=dev) * 0.05; bd = torch.randn(6040, device=dev)
         buf = torch.empty((6040, 3712), device=dev)
