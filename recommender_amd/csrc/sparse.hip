@@ -26,6 +26,16 @@
 // Bound: L2 bandwidth, nnz * N * 4 bytes of weight rows.
 #include "reco_common.h"
 
+// Weight rows in flight per wave (same-box A/B, round 3; AutoRec encoder N = 500 / Hybrid user and item encoders N = 256, ms):
+//   8 columns per lane:  2: 0.1338   3: 0.1332   4: 0.1318   6: 0.1330   8: 0.1375   12: 0.150   16: 0.174
+//   4 columns per lane:  8: 0.0760 / 0.111   16: 0.0775 / 0.1071   24: 0.090 / 0.119   32: 0.097 / 0.128
+#ifndef RECO_CSR_U8
+#define RECO_CSR_U8 4      // weight rows in flight per wave, 8 columns per lane (N > 256)
+#endif
+#ifndef RECO_CSR_U4
+#define RECO_CSR_U4 16     // 4 columns per lane (N <= 256)
+#endif
+
 namespace {
 
 constexpr int CSR_SEG_MAX = 256;
@@ -133,7 +143,7 @@ __global__ __launch_bounds__(256) void csr_linear_kernel(CsrArgs a)
 template <int CPL>
 __global__ __launch_bounds__(256) void csr_linear_wave_kernel(CsrArgs a)
 {
-    constexpr int U = CPL == 8 ? 8 : 16;
+    constexpr int U = CPL == 8 ? RECO_CSR_U8 : RECO_CSR_U4;
     constexpr int NV = CPL / 4;                              // float4 per lane and nonzero
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -30,6 +30,16 @@
 #ifndef RECO_TOPK_UN_MASKED
 #define RECO_TOPK_UN_MASKED 4
 #endif
+// Catalogue-length rows (one segment of a few thousand elements: 6,040 x 3,706 AutoRec / protocol rows) are another regime:
+// six float4 per lane cover 1,536 elements an iteration, so a 3,706-element row wastes a third of its last iteration and has
+// nothing to overlap with.  Same-box A/B (round 3), 6,038 x 3,533 unmasked / 6,040 x 3,706 masked by the rating matrix, ms:
+//   loads in flight 6 (4 masked): 0.0416 / 0.0479   4: 0.0384 / 0.0478   3: 0.0362 / 0.0450   2: 0.0370 / 0.0480   1: 0.0358 / 0.0460
+#ifndef RECO_TOPK_UN_SHORT
+#define RECO_TOPK_UN_SHORT 3  // segments up to RECO_TOPK_SHORT_SEG elements, masked or not
+#endif
+#ifndef RECO_TOPK_SHORT_SEG
+#define RECO_TOPK_SHORT_SEG 8192
+#endif
 #ifndef RECO_TOPK_WAVES
 #define RECO_TOPK_WAVES 3072
 #endif
@@ -64,7 +74,7 @@ struct TopkArgs {
 // wave and iteration); VEC = 1: any alignment, one float per lane and load, four in flight.
 // MASKED = false: no mask operand at all (the mask registers that travel with the scores cost the unmasked scan a third of
 // its speed on long rows: 0.354 -> 0.475 ms on 256 x 1M when they were carried unconditionally).
-template <int SLOTS, int VEC, bool MASKED>
+template <int SLOTS, int VEC, bool MASKED, bool SHORT>
 __global__ __launch_bounds__(256) void topk_scan_kernel(TopkArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -97,7 +107,7 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(TopkArgs a)
     // (Measured and dropped in round 2: a float pre-filter "score >= k-th score" in front of the key build, per 256-element block
     // 0.354 -> 0.383 ms and per 64-element offer 0.354 -> 0.353 ms on 256 x 1M, k = 100: the key build is not what bounds the scan.)
     if constexpr (VEC == 4) {
-        constexpr int UN = MASKED ? RECO_TOPK_UN_MASKED : RECO_TOPK_UN;
+        constexpr int UN = SHORT ? RECO_TOPK_UN_SHORT : (MASKED ? RECO_TOPK_UN_MASKED : RECO_TOPK_UN);
         // the masks travel with the scores: mk > 0 marks an excluded element.  (Read where they are applied -- after the scores
         // have arrived -- the mask loads were an exposed round trip per block: 6,040 x 3,706 with the float rating matrix as
         // the mask took 0.080 ms against 0.040 ms without a mask.)
@@ -424,10 +434,16 @@ int launch_topk_rows_ex(const float* scores, int64_t rows, int64_t N, int64_t ld
     // short rows keep whole 64-element chunks per offer (N = 100: 0.10 ms scalar vs 0.16 ms with quarter-filled chunks)
     const bool masked = exclude != nullptr || seen != nullptr;
     const dim3 grid((unsigned)blocks), block(256);
+    const bool shortseg = vec4 && a.seg <= RECO_TOPK_SHORT_SEG;      // catalogue-length rows: fewer loads in flight, less tail waste
 #define RECO_TOPK_LAUNCH(SLOTS, VEC)                                                                        \
     do {                                                                                                    \
-        if (masked) hipLaunchKernelGGL((topk_scan_kernel<SLOTS, VEC, true>), grid, block, 0, s, a);          \
-        else hipLaunchKernelGGL((topk_scan_kernel<SLOTS, VEC, false>), grid, block, 0, s, a);                \
+        if (shortseg && VEC == 4) {                                                                         \
+            if (masked) hipLaunchKernelGGL((topk_scan_kernel<SLOTS, VEC, true, VEC == 4>), grid, block, 0, s, a);    \
+            else hipLaunchKernelGGL((topk_scan_kernel<SLOTS, VEC, false, VEC == 4>), grid, block, 0, s, a);          \
+        } else {                                                                                            \
+            if (masked) hipLaunchKernelGGL((topk_scan_kernel<SLOTS, VEC, true, false>), grid, block, 0, s, a);       \
+            else hipLaunchKernelGGL((topk_scan_kernel<SLOTS, VEC, false, false>), grid, block, 0, s, a);             \
+        }                                                                                                   \
     } while (0)
     {
         ProfScope prof(s, RECO_PROF_TOPK);
