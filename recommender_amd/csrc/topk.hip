@@ -46,6 +46,9 @@
 #ifndef RECO_TOPK_RING
 #define RECO_TOPK_RING 64    // pending candidates per wave before a flush
 #endif
+#ifndef RECO_TOPK_LANE_SELECT
+#define RECO_TOPK_LANE_SELECT 1   // 0: the one-pass lane kernel for every short-row shape (A/B)
+#endif
 #ifndef RECO_TOPK_WAVES_MASKED
 #define RECO_TOPK_WAVES_MASKED 4096
 #endif
@@ -344,6 +347,158 @@ __global__ __launch_bounds__(256) void topk_lane_kernel(TopkArgs a)
     }
 }
 
+// Short rows with 16-byte aligned starts (the protocol's 100 scores per row): select, then order.  The insertion above spends
+// 4 K selects per element on carrying the ids along; here a lane first finds the VALUES of the K best keys with one
+// v_med3_u32 per list slot (new l[j] = med3(key, l[j-1], l[j]) is the sorted insertion of a key into a descending list), then
+// marks the elements that reach the K-th key in a per-lane bit mask, and only those ~K elements go through the id-carrying
+// insertion, in position order (so equal keys keep the ascending-position rule): ~3,200 instead of ~5,600 instructions per 64 rows.
+// What that alone bought was 0.036 -> 0.034 ms: the wave timeline (tools/lane_trace.py) showed that ONE wave issues a VALU
+// instruction every ~8 cycles, a SIMD one every 4 -- it takes two waves per SIMD to use the ALU -- and with whole rows in LDS
+// (25.6 KB per wave) six waves fit a CU where the grid brings seven to ten.  So a row goes through LDS in SEGMENTS of 52 columns
+// (13.3 KB per wave: every wave of the grid is resident at once): the key list runs on across segments, a segment's marked
+// elements are those that reach the K-th key SO FAR, and they are inserted into the one (key, id) list -- the result is the
+// top K of (top K of the earlier segments + this segment's entrants), in position order as before: 0.0356 -> 0.0253 ms
+// (115,056 x 100, k = 10, same-box A/B); DESIGN section 3 K-d has the timeline.
+// One wave per workgroup; its rows come in through LDS-direct loads (no staging registers, no barrier anywhere), 13 sixteen-byte
+// slots per row and segment -- an odd stride, so a lane's float4 reads of its own row are conflict-free.  Keys are written back
+// over the scores so the later passes skip float_key.
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+#ifdef RECO_DIAG_LANE_TRACE         // diagnostic builds only: per-wave start / end time and placement (tools/lane_trace.py)
+static __device__ unsigned long long g_lane_trace[3 * 4096];
+#endif
+
+constexpr int LSEL_SLOTS = 13;                 // float4 slots per row and segment
+constexpr int LSEL_COLS = 4 * LSEL_SLOTS;      // 52 columns
+
+template <int K>
+__global__ __launch_bounds__(64) void topk_lane_select_kernel(TopkArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float s_rows[64 * LSEL_COLS];    // [64 rows][13 slots]
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#ifdef RECO_DIAG_LANE_TRACE
+    const unsigned long long trace_t0 = wall_clock64();
+#endif
+    const int lane = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int n4 = (int)(a.N >> 2);
+    uint32_t* krow = reinterpret_cast<uint32_t*>(s_rows) + lane * LSEL_COLS;
+
+    uint32_t lv[K];                  // the K best key values so far (pass 1)
+    uint32_t lk[K];                  // the K best (key, id) so far (pass 3)
+    int32_t li[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { lv[j] = 0u; lk[j] = 0u; li[j] = -1; }       // 0 is below every real key (float_key(-inf) = 0x007fffff)
+
+    for (int c_lo = 0; c_lo < n4; c_lo += LSEL_SLOTS) {
+        const int ns = n4 - c_lo < LSEL_SLOTS ? n4 - c_lo : LSEL_SLOTS;       // float4 slots of this segment
+        {
+            typedef const __attribute__((address_space(1))) void* gptr_t;
+            typedef __attribute__((address_space(3))) void* lptr_t;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the previous segment's LDS reads are done
+#pragma unroll
+            for (int i = 0; i < LSEL_SLOTS; ++i) {
+                const int p = i * 64 + lane;                                  // LDS slot p = (row, col): the lane's 16 bytes land there
+                const int rr = (p * 5042) >> 16;                              // p / 13 for p < 6,570
+                int col = p - LSEL_SLOTS * rr;
+                if (col >= ns) col = ns - 1;                                  // slots past the row's end repeat the last one (never read)
+                int64_t row = r0 + rr;
+                if (row >= a.rows) row = a.rows - 1;                          // the ragged last workgroup: a valid row, result unused
+                __builtin_amdgcn_global_load_lds((gptr_t)(a.scores + row * a.ld + 4 * (c_lo + col)), (lptr_t)(s_rows + i * 256), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // pass 1: the K best key VALUES so far (with multiplicity), keys written back over the scores
+        f32x4 cur = *reinterpret_cast<const f32x4*>(krow);
+#pragma unroll
+        for (int c = 0; c < LSEL_SLOTS; ++c) {
+            if (c < ns) {                                                    // uniform
+                f32x4 nxt = cur;
+                if (c + 1 < ns) nxt = *reinterpret_cast<const f32x4*>(krow + 4 * (c + 1));
+                u32x4 kk;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const uint32_t key = float_key(cur[t]);
+                    kk[t] = key;
+#pragma unroll
+                    for (int j = K - 1; j >= 1; --j) lv[j] = umed3(key, lv[j - 1], lv[j]);
+                    lv[0] = key > lv[0] ? key : lv[0];
+                }
+                *reinterpret_cast<u32x4*>(krow + 4 * c) = kk;
+                cur = nxt;
+            }
+        }
+        uint32_t thr = lv[0];
+#pragma unroll
+        for (int j = 1; j < K; ++j) thr = (j < a.k) ? lv[j] : thr;           // the k-th best key so far
+
+        // pass 2: which elements of this segment reach it.  A mask word is shifted left as it fills (one v_cmp + one add-with-carry
+        // per element), so the EARLIEST element of a word sits in its highest bit: element e of the segment is bit 31 - e of m0
+        // (e < 32) or bit 51 - e of m1
+        uint32_t m0 = 0u, m1 = 0u;
+#pragma unroll
+        for (int c = 0; c < LSEL_SLOTS; ++c) {
+            if (c < ns) {                                                    // uniform
+                const u32x4 kk = *reinterpret_cast<const u32x4*>(krow + 4 * c);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (c < 8) m0 = m0 + m0 + (kk[t] >= thr ? 1u : 0u);
+                    else m1 = m1 + m1 + (kk[t] >= thr ? 1u : 0u);
+                }
+            } else {
+                if (c < 8) m0 <<= 4;
+                else m1 <<= 4;
+            }
+        }
+
+        // pass 3: the marked elements, in position order, through the id-carrying insertion (keys by v_med3, ids by selects)
+        for (;;) {
+            const uint32_t any = m0 | m1;
+            if (__ballot(any != 0u) == 0ull) break;
+            const uint32_t mw = m0 ? m0 : m1;
+            const int lz = any ? __builtin_clz(mw) : 0;
+            const int pl = m0 ? lz : 32 + lz - (64 - LSEL_COLS);             // position inside the segment (m1 holds 20 elements)
+            const uint32_t clr = ~(0x80000000u >> lz);
+            if (m0) m0 &= clr;
+            else m1 &= any ? clr : 0u;
+            const uint32_t key = any ? krow[any ? pl : 0] : 0u;              // 0 never enters
+            const int32_t pos = 4 * c_lo + pl;
+#pragma unroll
+            for (int j = K - 1; j >= 1; --j) {
+                const bool here = key > lk[j], above = key > lk[j - 1];
+                li[j] = above ? li[j - 1] : (here ? pos : li[j]);
+                lk[j] = umed3(key, lk[j - 1], lk[j]);
+            }
+            li[0] = key > lk[0] ? pos : li[0];
+            lk[0] = key > lk[0] ? key : lk[0];
+        }
+    }
+#ifdef RECO_DIAG_LANE_TRACE
+    if (lane == 0 && blockIdx.x < 4096) {
+        g_lane_trace[3 * blockIdx.x + 0] = trace_t0;
+        g_lane_trace[3 * blockIdx.x + 1] = wall_clock64();
+        g_lane_trace[3 * blockIdx.x + 2] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) |      // HW_ID
+                                           ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);  // XCC_ID
+    }
+#endif
+    const int64_t row = r0 + lane;
+    if (row < a.rows) {
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (j < a.k) {
+                a.out_ids[row * a.k + j] = li[j];
+                a.out_vals[row * a.k + j] = key_float(lk[j]);
+            }
+    }
+}
+
 int choose_splits(int64_t rows, int64_t N, int k, bool masked)
 {
     // enough waves to cover the loads (3-4 per SIMD) while keeping segments long enough to amortise the list: every segment
@@ -407,6 +562,14 @@ int launch_topk_rows_ex(const float* scores, int64_t rows, int64_t N, int64_t ld
         RECO_REQUIRE(lblocks < (1ll << 31), "topk grid too large");
         const bool v4 = ld % 4 == 0 && (uintptr_t)scores % 16 == 0;
         ProfScope prof(s, RECO_PROF_TOPK);
+        if (RECO_TOPK_LANE_SELECT && v4 && N % 4 == 0 && N <= 160) {         // rows of float4s: select-then-order, <= 4 segments
+            const int64_t sblocks = ceil_div64(rows, 64);
+            RECO_REQUIRE(sblocks < (1ll << 31), "topk grid too large");
+            if (k <= 10) hipLaunchKernelGGL(topk_lane_select_kernel<10>, dim3((unsigned)sblocks), dim3(64), 0, s, a);
+            else hipLaunchKernelGGL(topk_lane_select_kernel<16>, dim3((unsigned)sblocks), dim3(64), 0, s, a);
+            RECO_CHECK_LAUNCH();
+            return RECO_OK;
+        }
         if (k <= 10) {
             if (v4) hipLaunchKernelGGL((topk_lane_kernel<10, 4>), dim3((unsigned)lblocks), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((topk_lane_kernel<10, 1>), dim3((unsigned)lblocks), dim3(256), 0, s, a);
@@ -468,3 +631,12 @@ int launch_topk_rows_ex(const float* scores, int64_t rows, int64_t N, int64_t ld
     }
     return RECO_OK;
 }
+
+#ifdef RECO_DIAG_LANE_TRACE
+extern "C" int reco_debug_lane_trace(unsigned long long* host_out, int words)
+{
+    if (words > 3 * 4096) words = 3 * 4096;
+    RECO_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_lane_trace), (size_t)words * sizeof(unsigned long long)));
+    return RECO_OK;
+}
+#endif

@@ -581,11 +581,18 @@ def test_tower_random_request_sweep(g2, tag, tower_precision):
 
 def test_topk_many_short_rows_lane_kernel():
     """>= 32,768 short rows take the lane-per-row kernel (the 99-negative protocol shape): every row length class around the
-    32-column staging slab, k on both register-list sizes, aligned and unaligned leading dimensions, ties, NaN / inf / -0.0."""
+    32-column staging slab, k on both register-list sizes, aligned and unaligned leading dimensions, ties, NaN / inf / -0.0.
+    Rows of whole float4s up to 160 scores (N = 100 is the protocol's) take topk_lane_select_kernel: one to four 52-column
+    segments, ragged last segment and last workgroup, padded leading dimension, k below and at the list size, an all-equal row
+    (every element is marked), heavy ties."""
     from recommender_amd import ops
     rng = np.random.default_rng(5)
     for case, (rows, N, k, pad) in enumerate(((40000, 100, 10, 0), (33000, 37, 3, 0), (32768, 130, 16, 2), (35001, 31, 10, 1),
-                                              (32769, 64, 11, 0), (33333, 512, 1, 0), (34000, 16, 16, 3))):
+                                              (32769, 64, 11, 0), (33333, 512, 1, 0), (34000, 16, 16, 3),
+                                              # 16-byte aligned rows of float4s: the select-then-order kernel, 1 to 4 segments
+                                              (33001, 100, 10, 0), (32800, 100, 16, 0), (33000, 36, 7, 0), (32770, 124, 10, 0),
+                                              (32773, 12, 10, 0), (32790, 20, 13, 0), (115056, 100, 10, 0), (32800, 160, 10, 0),
+                                              (33000, 104, 10, 4), (33003, 52, 10, 0), (33000, 56, 5, 8), (32769, 156, 16, 0))):
         full = rng.standard_normal((rows, N + pad)).astype(np.float32)
         if case % 2:
             full = np.round(full * 2) / 2                        # heavy ties: the lower position must win

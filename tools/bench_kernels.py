@@ -127,7 +127,7 @@ def section_cfg1(model, dev, steps, warmup):
     ms, seq = timed(step, steps, warmup, dev)
     pair = kernel_rec("tower_pairs_q_kernel<32,true,12 waves>", _pick(seq, _lib.PROF_TOWER), "mfma", B * NEUMF_EXEC,
                       "%d pairs x 20,768 FLOP executed (86,176 algorithmic: layer 1 is read from the handle's P/Q projections)" % B)
-    lane = kernel_rec("topk_lane_kernel<10>", _pick(seq, _lib.PROF_TOPK), "hbm", cases * (4 * width + 8 * k),
+    lane = kernel_rec("topk_lane_select_kernel<10>", _pick(seq, _lib.PROF_TOPK), "hbm", cases * (4 * width + 8 * k),
                       "%d lists x (400 B of scores read + 80 B written)" % cases)
     # the whole evaluator once, host lists in -> HR / NDCG out, not part of the timed steps
     from recommender_amd.evaluate import evaluate_protocol

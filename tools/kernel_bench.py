@@ -129,7 +129,7 @@ def bench_topk():
     for rows, N, k in ((6038, 3533, 10), (6040, 3706, 10), (256, 1_000_000, 100), (115056, 100, 10)):
         s = torch.randn(rows, N, device=dev)
         ms = timeit(lambda: ops.topk_rows(s, k))
-        emit("topk_lane_kernel" if (rows >= 32768 and N <= 512 and k <= 16) else "topk_scan_kernel(+merge)", "rows=%d N=%d k=%d" % (rows, N, k), ms, "hbm", rows * (4 * N + 8 * k), "4*N + 8*K bytes per row")
+        emit(("topk_lane_select_kernel" if (N % 4 == 0 and N <= 160) else "topk_lane_kernel") if (rows >= 32768 and N <= 512 and k <= 16) else "topk_scan_kernel(+merge)", "rows=%d N=%d k=%d" % (rows, N, k), ms, "hbm", rows * (4 * N + 8 * k), "4*N + 8*K bytes per row")
         del s
 
 
