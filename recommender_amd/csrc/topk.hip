@@ -34,8 +34,15 @@
 // six float4 per lane cover 1,536 elements an iteration, so a 3,706-element row wastes a third of its last iteration and has
 // nothing to overlap with.  Same-box A/B (round 3), 6,038 x 3,533 unmasked / 6,040 x 3,706 masked by the rating matrix, ms:
 //   loads in flight 6 (4 masked): 0.0416 / 0.0479   4: 0.0384 / 0.0478   3: 0.0362 / 0.0450   2: 0.0370 / 0.0480   1: 0.0358 / 0.0460
+// Then the wave timeline of the lane kernel (below) showed what such launches are short of: waves per SIMD.  6,040 one-wave rows
+// are 5.9 waves per SIMD, the kernel held 102 / 130 VGPRs (4 / 3 waves per SIMD: two rounds).  With ONE float4 in flight per
+// lane and the register budget of six waves per SIMD (no spill; two in flight spill under the mask) the whole grid is resident
+// at once: 0.0362 / 0.0455 -> 0.0292 / 0.0348 ms.
 #ifndef RECO_TOPK_UN_SHORT
-#define RECO_TOPK_UN_SHORT 3  // segments up to RECO_TOPK_SHORT_SEG elements, masked or not
+#define RECO_TOPK_UN_SHORT 1  // segments up to RECO_TOPK_SHORT_SEG elements
+#endif
+#ifndef RECO_TOPK_UN_SHORT_MASKED
+#define RECO_TOPK_UN_SHORT_MASKED 1
 #endif
 #ifndef RECO_TOPK_SHORT_SEG
 #define RECO_TOPK_SHORT_SEG 8192
@@ -77,8 +84,14 @@ struct TopkArgs {
 // wave and iteration); VEC = 1: any alignment, one float per lane and load, four in flight.
 // MASKED = false: no mask operand at all (the mask registers that travel with the scores cost the unmasked scan a third of
 // its speed on long rows: 0.354 -> 0.475 ms on 256 x 1M when they were carried unconditionally).
+#ifndef RECO_TOPK_SHORT_OCC
+#define RECO_TOPK_SHORT_OCC 6          // waves per SIMD the short-segment scans are compiled for (see RECO_TOPK_UN_SHORT)
+#endif
+#ifndef RECO_TOPK_SHORT_OCC_MASKED
+#define RECO_TOPK_SHORT_OCC_MASKED 6
+#endif
 template <int SLOTS, int VEC, bool MASKED, bool SHORT>
-__global__ __launch_bounds__(256) void topk_scan_kernel(TopkArgs a)
+__global__ __launch_bounds__(256, SHORT ? (MASKED ? RECO_TOPK_SHORT_OCC_MASKED : RECO_TOPK_SHORT_OCC) : 1) void topk_scan_kernel(TopkArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -110,7 +123,7 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(TopkArgs a)
     // (Measured and dropped in round 2: a float pre-filter "score >= k-th score" in front of the key build, per 256-element block
     // 0.354 -> 0.383 ms and per 64-element offer 0.354 -> 0.353 ms on 256 x 1M, k = 100: the key build is not what bounds the scan.)
     if constexpr (VEC == 4) {
-        constexpr int UN = SHORT ? RECO_TOPK_UN_SHORT : (MASKED ? RECO_TOPK_UN_MASKED : RECO_TOPK_UN);
+        constexpr int UN = SHORT ? (MASKED ? RECO_TOPK_UN_SHORT_MASKED : RECO_TOPK_UN_SHORT) : (MASKED ? RECO_TOPK_UN_MASKED : RECO_TOPK_UN);
         // the masks travel with the scores: mk > 0 marks an excluded element.  (Read where they are applied -- after the scores
         // have arrived -- the mask loads were an exposed round trip per block: 6,040 x 3,706 with the float rating matrix as
         // the mask took 0.080 ms against 0.040 ms without a mask.)
