@@ -52,23 +52,50 @@ __device__ __forceinline__ void mlp2_prefetch(const float* __restrict__ wrow, in
 
 __device__ __forceinline__ f32x16 mlp2_block(const float* __restrict__ wrow, const float* xrow, int nq, f32x4* a, f32x16 acc)
 {
-    for (int q0 = 0; q0 < nq; q0 += MLP2_AHEAD) {
+    // Whole groups of AHEAD quads run without a branch: the group's LDS reads are issued up front and the refills of the weight
+    // window sit between the MFMAs, so nothing but the accumulator chain itself orders the 4 AHEAD MFMAs (with a guard per quad
+    // every quad paid a full L2 round trip: 525 cycles per 4 MFMAs on the workgroup timeline, tools/mlp2_trace.py).
+    int q0 = 0;
+    for (; q0 + MLP2_AHEAD <= nq; q0 += MLP2_AHEAD) {
+        f32x4 x[MLP2_AHEAD];
+#pragma unroll
+        for (int p = 0; p < MLP2_AHEAD; ++p) x[p] = *reinterpret_cast<const f32x4*>(xrow + 8 * (q0 + p));
 #pragma unroll
         for (int p = 0; p < MLP2_AHEAD; ++p) {
-            const int q = q0 + p;
-            if (q < nq) {                             // uniform
-                const f32x4 av = a[p];
-                if (q + MLP2_AHEAD < nq) a[p] = *reinterpret_cast<const f32x4*>(wrow + 8 * (q + MLP2_AHEAD));
-                const f32x4 x = *reinterpret_cast<const f32x4*>(xrow + 8 * q);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, x.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, x.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, x.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, x.w, acc, 0, 0, 0);
-            }
+            const f32x4 av = a[p];
+            // the refill is unconditional (past the end it re-reads the last quad): a guard here is a branch, and behind a branch
+            // the compiler waits for EVERY outstanding load (s_waitcnt vmcnt(0) after each refill: the window was no window)
+            int qn = q0 + p + MLP2_AHEAD;
+            qn = qn < nq ? qn : nq - 1;
+            a[p] = *reinterpret_cast<const f32x4*>(wrow + 8 * qn);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, x[p].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, x[p].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, x[p].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, x[p].w, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);          // keep the refill here (left alone the scheduler sinks all AHEAD of them to the loop's end)
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < MLP2_AHEAD; ++p) {                              // the ragged last group (K not a multiple of 8 AHEAD)
+        const int q = q0 + p;
+        if (q < nq) {                                                   // uniform
+            const f32x4 av = a[p];
+            const f32x4 x = *reinterpret_cast<const f32x4*>(xrow + 8 * q);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, x.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, x.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, x.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, x.w, acc, 0, 0, 0);
         }
     }
     return acc;
 }
+
+#ifdef RECO_DIAG_MLP2_TRACE         // diagnostic builds only: phase time stamps of every workgroup's wave 0 (tools/mlp2_trace.py)
+static __device__ unsigned long long g_mlp2_trace[8 * 1024];
+#define MLP2_STAMP(i) do { if (tid == 0 && blockIdx.x < 1024) g_mlp2_trace[8 * blockIdx.x + (i)] = wall_clock64(); } while (0)
+#else
+#define MLP2_STAMP(i) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(256) void mlp2_kernel(Mlp2Args a)
 {
@@ -81,6 +108,7 @@ __global__ __launch_bounds__(256) void mlp2_kernel(Mlp2Args a)
     const int j = lane & 31, h = lane >> 5;
     const int64_t m0 = (int64_t)blockIdx.x * 32;
 
+    MLP2_STAMP(0);
     f32x4 aw[MLP2_AHEAD];
     if (32 * wave < a.N2) mlp2_prefetch(a.W2 + (int64_t)(32 * wave + j) * a.K1 + 4 * h, a.K1 / 8, aw);
     // stage the 32 rows (rows past M repeat the last one; their results are not stored)
@@ -92,6 +120,7 @@ __global__ __launch_bounds__(256) void mlp2_kernel(Mlp2Args a)
         *reinterpret_cast<f32x4*>(s_x + r * LX + 4 * c) = *reinterpret_cast<const f32x4*>(a.X + m * a.ldx + 4 * c);
     }
     __syncthreads();
+    MLP2_STAMP(1);
 
     // first layer: wave w -> features [32 w, 32 w + 32) (and + 128, ... for wider layers)
     for (int f0 = 32 * wave; f0 < a.N2; f0 += 128) {
@@ -111,8 +140,10 @@ __global__ __launch_bounds__(256) void mlp2_kernel(Mlp2Args a)
             *reinterpret_cast<f32x4*>(s_2 + j * L2 + f0 + 8 * rq + 4 * h) = v;
         }
     }
+    MLP2_STAMP(2);
     if (32 * wave < a.N3) mlp2_prefetch(a.W3 + (int64_t)(32 * wave + j) * a.N2 + 4 * h, a.N2 / 8, aw);
     __syncthreads();
+    MLP2_STAMP(3);
 
     // second layer: wave w -> features [32 w, 32 w + 32), [32 w + 128, ...)
     for (int f0 = 32 * wave; f0 < a.N3; f0 += 128) {
@@ -135,6 +166,11 @@ __global__ __launch_bounds__(256) void mlp2_kernel(Mlp2Args a)
             }
         }
     }
+    MLP2_STAMP(4);
+#ifdef RECO_DIAG_MLP2_TRACE
+    if (tid == 0 && blockIdx.x < 1024)
+        g_mlp2_trace[8 * blockIdx.x + 5] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+#endif
 }
 
 }  // namespace
@@ -172,3 +208,12 @@ extern "C" int reco_mlp2_f32(const float* X, int64_t ldx, int64_t M, int64_t K1,
     RECO_CHECK_LAUNCH();
     return RECO_OK;
 }
+
+#ifdef RECO_DIAG_MLP2_TRACE
+extern "C" int reco_debug_mlp2_trace(unsigned long long* host_out, int words)
+{
+    if (words > 8 * 1024) words = 8 * 1024;
+    RECO_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_mlp2_trace), (size_t)words * sizeof(unsigned long long)));
+    return RECO_OK;
+}
+#endif

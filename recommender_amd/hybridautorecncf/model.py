@@ -10,6 +10,7 @@ reference semantics (encoders, decoders and head for every pair of the batch).  
 full-catalog path (cfg4): encode every user and item ONCE, then the fused head over all pairs --
 instead of the reference's O(blocks x items) full-model loop (hybridautorecncf.ipynb cell 13).
 """
+import os
 import weakref
 
 import torch
@@ -20,6 +21,17 @@ from .. import ops
 _tower_cache = weakref.WeakKeyDictionary()
 _weight_cache = weakref.WeakKeyDictionary()      # AutoEncoder -> {id(Sequential): (signature, [(weight, bias) on device])}
 _csr_cache = weakref.WeakKeyDictionary()         # HybridAutoRecNCF -> (attached tensor, its version, (CSR of R, CSR of R^T))
+
+
+_side_streams = {}                               # device index -> the stream the item encoder runs on beside the user encoder
+
+
+def _side_stream(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _side_streams.get(idx)
+    if st is None:
+        st = _side_streams[idx] = torch.cuda.Stream(device=idx)
+    return st
 
 
 def _f32_on(t, device):
@@ -218,10 +230,26 @@ class HybridAutoRecNCF(nn.Module):
         device = rating_matrix.device if rating_matrix.is_cuda else torch.device("cuda", torch.cuda.current_device())
         R = rating_matrix.to(device=device, dtype=torch.float32).contiguous()
         hit = _csr_cache.get(self)
-        if hit is not None and hit[0] is rating_matrix and hit[1] == rating_matrix._version:
-            zu = self.user_autorec.encode(hit[2][0])
-            zi = self.item_autorec.encode(hit[2][1])
+        sparse = hit is not None and hit[0] is rating_matrix and hit[1] == rating_matrix._version
+        xu = hit[2][0] if sparse else R
+        xi = hit[2][1] if sparse else R
+        # The two encoders are independent chains of short launches (a CSR or split-K first layer, then the narrow layers): the
+        # item side runs on a second stream beside the user side and joins before the head (fork / join by events, so the pattern
+        # also captures into a HIP graph).  RECO_HYBRID_STREAMS=0 keeps both on the caller's stream.
+        if os.environ.get("RECO_HYBRID_STREAMS", "1") != "0":
+            cur = torch.cuda.current_stream(device)
+            side = _side_stream(device)
+            fork = torch.cuda.Event()
+            fork.record(cur)
+            side.wait_event(fork)
+            with torch.cuda.stream(side):
+                zi = self.item_autorec.encode(xi) if sparse else self.item_autorec.encode(xi, transposed=True)
+                join = torch.cuda.Event()
+                join.record(side)
+            zu = self.user_autorec.encode(xu)
+            cur.wait_event(join)
+            zi.record_stream(cur)              # allocated on the side stream's pool, consumed on the caller's
         else:
-            zu = self.user_autorec.encode(R)
-            zi = self.item_autorec.encode(R, transposed=True)
+            zu = self.user_autorec.encode(xu)
+            zi = self.item_autorec.encode(xi) if sparse else self.item_autorec.encode(xi, transposed=True)
         return self.ncf.score_matrix(zu, zi, k, exclude, seen=R if (mask_seen and k is not None) else None)
