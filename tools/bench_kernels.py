@@ -234,8 +234,20 @@ def section_cfg4(dev, steps, warmup):
     for tag in ("dense", "csr"):
         if tag == "csr":
             h.attach_ratings(R)
-        ms, seq = timed(lambda: h.score_all(R, k=10), steps, warmup, dev, 40)
-        part = {"ms_per_step": ms, "pairs_per_s": pairs / ms * 1e3, "kernels": []}
+        # the step as the product runs it (item encoder on a side stream beside the user encoder), then once more with both sides
+        # on one stream for the per-kernel records: durations of kernels that overlap on the GPU do not add up to anything
+        ms, _ = timed(lambda: h.score_all(R, k=10), steps, warmup, dev, 40)
+        was = os.environ.get("RECO_HYBRID_STREAMS")
+        os.environ["RECO_HYBRID_STREAMS"] = "0"
+        try:
+            ms_one, seq = timed(lambda: h.score_all(R, k=10), steps, warmup, dev, 40)
+        finally:
+            if was is None:
+                os.environ.pop("RECO_HYBRID_STREAMS", None)
+            else:
+                os.environ["RECO_HYBRID_STREAMS"] = was
+        part = {"ms_per_step": ms, "ms_per_step_one_stream": ms_one, "pairs_per_s": pairs / ms * 1e3, "kernels": [],
+                "kernels_note": "per-kernel durations from the one-stream run (RECO_HYBRID_STREAMS=0); ms_per_step is the two-stream step"}
         tw = _pick(seq, _lib.PROF_TOWER)
         first_tower = next((n for n, x in enumerate(seq) if x[0] == _lib.PROF_TOWER), len(seq))
         enc_ms = sum(x[1] for x in seq[:max(first_tower - 2, 0)])           # everything before the head's two projection GEMMs
