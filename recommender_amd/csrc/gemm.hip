@@ -80,6 +80,9 @@ __device__ __forceinline__ float apply_act(float v, int act, float lo, float hi)
     }
 }
 
+// transposed-A staging: chunk position XOR of a tile row (store_tile / fragment reads of linear_kernel)
+__device__ __forceinline__ int at_swz(int row) { return (row >> 4) & 3; }
+
 // 4 consecutive k of one row.  VEC = 4 / 2 / 1: widest load the row alignment allows (K = 3706 rows are only 8-B aligned).
 template <int VEC, bool GUARD>
 __device__ __forceinline__ f32x4 load_k4(const float* row, int64_t k, int64_t K)
@@ -293,13 +296,19 @@ __global__ __launch_bounds__(256, DMAT ? (ONE ? 4 : 2) : 1) void linear_kernel(L
         float* s_a = smem + buf * BUF;
         float* s_b = s_a + BM * LSD;
         if constexpr (AT) {   // [m][k] image from k-major registers: row 4 tc + i gets element i of each of the RA loads
+            // Consecutive lanes write rows FOUR apart at the same k chunk: with the padded stride alone 16 lanes land in 4 distinct
+            // 16-byte slots (36 x 4 tc mod 64 banks = 16 tc mod 64), a 4-way conflict on every write of the transposition.  The
+            // chunk position is therefore XORed with bits 4..5 of the row (at_swz): writes and fragment reads are then both
+            // conflict-free (brute-forced over stride x shift x mask, tools/lds_swizzle_search.py).
 #pragma unroll
             for (int i4 = 0; i4 < 4; ++i4) {
-                float* d = s_a + (4 * tc + i4) * LS + RA * tkb;
+                const int row = 4 * tc + i4;
                 if constexpr (RA == 4) {
+                    float* d = s_a + row * LS + 4 * (tkb ^ at_swz(row));
                     *reinterpret_cast<f32x4*>(d) = f32x4{ra[0][i4], ra[1][i4], ra[2][i4], ra[3][i4]};
                 } else {
                     typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    float* d = s_a + row * LS + 4 * ((tkb >> 1) ^ at_swz(row)) + 2 * (tkb & 1);
                     *reinterpret_cast<f32x2*>(d) = f32x2{ra[0][i4], ra[1][i4]};
                 }
             }
@@ -368,14 +377,17 @@ __global__ __launch_bounds__(256, DMAT ? (ONE ? 4 : 2) : 1) void linear_kernel(L
                             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][ta[term]], fb[tn][tb[term]], acc[tm][tn], 0, 0, 0);
             }
         } else {
-        const float* s_a = smem + (t & (NBUF - 1)) * BUF + (wm * (BM / 2) + i) * LSD + (DMA ? 0 : 4 * h);
+        const float* s_a = smem + (t & (NBUF - 1)) * BUF + (wm * (BM / 2) + i) * LSD + ((DMA || AT) ? 0 : 4 * h);
         const float* s_b = smem + (t & (NBUF - 1)) * BUF + BM * LSD + (wn * (BN / 2) + i) * LSD + (DMA ? 0 : 4 * h);
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {
             f32x4 fa[TM], fb[TN];
             const int fo = DMA ? 4 * ((2 * q + h) ^ sw_f) : 8 * q;      // chunk 2 q + h of the row (DMA: at its swizzled position)
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) fa[tm] = *reinterpret_cast<const f32x4*>(s_a + tm * 32 * LSD + fo);
+            for (int tm = 0; tm < TM; ++tm) {
+                if constexpr (AT) fa[tm] = *reinterpret_cast<const f32x4*>(s_a + tm * 32 * LSD + 4 * ((2 * q + h) ^ at_swz(wm * (BM / 2) + tm * 32 + i)));
+                else fa[tm] = *reinterpret_cast<const f32x4*>(s_a + tm * 32 * LSD + fo);
+            }
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) fb[tn] = *reinterpret_cast<const f32x4*>(s_b + tn * 32 * LSD + fo);
 #pragma unroll
