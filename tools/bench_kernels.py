@@ -131,10 +131,11 @@ def section_cfg1(model, dev, steps, warmup):
                       "%d lists x (400 B of scores read + 80 B written)" % cases)
     # the whole evaluator once, host lists in -> HR / NDCG out, not part of the timed steps
     from recommender_amd.evaluate import evaluate_protocol
-    evaluate_protocol(model, users.numpy(), items.numpy(), k)
+    users_h, items_h = users.numpy().astype(np.int32), items.numpy().astype(np.int32)    # as data_io.read_test_negative returns them
+    evaluate_protocol(model, users_h, items_h, k)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    hr, nd, _, _ = evaluate_protocol(model, users.numpy(), items.numpy(), k)
+    hr, nd, _, _ = evaluate_protocol(model, users_h, items_h, k)
     e2e = (time.perf_counter() - t0) * 1e3
     out = {"workload": "cfg1 at the reference's full protocol size: %d test cases x %d candidates = %d pairs, forward(user, item) + per-case "
                        "top-%d (ncf.ipynb cell 8); ids resident in HBM" % (cases, width, B, k),
@@ -143,7 +144,7 @@ def section_cfg1(model, dev, steps, warmup):
                            "note": "reference FLOP count over the fp32 MFMA peak; not a hardware fraction"},
            "topk": lane,
            "evaluate_protocol_e2e_ms": e2e, "hr_at_10": hr, "ndcg_at_10": nd,
-           "e2e_note": "host id lists in -> HR@10 / NDCG@10 out, one call (PCIe upload + kernels + host metrics); random-init weights"}
+           "e2e_note": "host int32 id lists (as the protocol reader returns them) in -> HR@10 / NDCG@10 out, one call (PCIe upload + kernels + host metrics); random-init weights"}
     out.update(pair)
     return out
 
