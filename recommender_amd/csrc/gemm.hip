@@ -120,9 +120,17 @@ __device__ __forceinline__ f32x4 load_k4(const float* row, int64_t k, int64_t K)
 // Same-box A/B (tools/gemm_variant_ab.sh): AutoRec decoder 0.243 -> 0.234 ms, split-K encoder 0.237 -> 0.232, 4096^3 1.12 -> 1.095;
 // single-buffered launches with fewer than 12 K tiles lose (a workgroup has nothing in flight while it waits: the Hybrid
 // encoders' K = 256 / 128 layers +1.5 %) and keep the register path.
+#ifdef RECO_DIAG_GEMM_TRACE         // diagnostic builds only: phase time stamps of every workgroup's thread 0 (tools/gemm_trace.py)
+static __device__ unsigned long long g_gemm_trace[8 * 8192];
+#define GEMM_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_trace[8 * blockIdx.x + (i)] = wall_clock64(); } while (0)
+#else
+#define GEMM_STAMP(i) do { } while (0)
+#endif
+
 template <int BM, int BN, int VEC, bool AT, bool SPLIT, bool ONE, bool DMAT>
 __global__ __launch_bounds__(256, DMAT ? (ONE ? 4 : 2) : 1) void linear_kernel(LinArgs a)
 {
+    GEMM_STAMP(0);
     static_assert(!DMAT || (!AT && !SPLIT && VEC == 4), "LDS-direct staging: plain exact form with 16-byte aligned rows only");
     constexpr bool DMA = DMAT;
     constexpr int LSD = DMA ? BK : LS;          // LDS row stride of the exact form
@@ -345,6 +353,7 @@ __global__ __launch_bounds__(256, DMAT ? (ONE ? 4 : 2) : 1) void linear_kernel(L
         store_tile(0);
     }
     __syncthreads();
+    GEMM_STAMP(1);
 
     for (int64_t t = 0; t < nt; ++t) {
 #ifdef RECO_ABL_GEMM_NO_LOAD       // timing-only ablation: every K tile re-stages the first one's registers
@@ -413,6 +422,7 @@ __global__ __launch_bounds__(256, DMAT ? (ONE ? 4 : 2) : 1) void linear_kernel(L
         __syncthreads();
     }
 
+    GEMM_STAMP(2);
     // epilogue: D[row = (r&3) + 8 (r>>2) + 4 h][col = lane & 31]
     const float osc = a.out_scale ? a.out_scale[0] : 1.f;
     const bool brows = a.bias && a.bias_rows, bcols = a.bias && !a.bias_rows;
@@ -452,7 +462,21 @@ __global__ __launch_bounds__(256, DMAT ? (ONE ? 4 : 2) : 1) void linear_kernel(L
             }
         }
     }
+    GEMM_STAMP(3);
+#ifdef RECO_DIAG_GEMM_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 8192)
+        g_gemm_trace[8 * blockIdx.x + 4] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+#endif
 }
+
+#ifdef RECO_DIAG_GEMM_TRACE
+extern "C" int reco_debug_gemm_trace(unsigned long long* host_out, int words)
+{
+    if (words > 8 * 8192) words = 8 * 8192;
+    RECO_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_trace), (size_t)words * sizeof(unsigned long long)));
+    return RECO_OK;
+}
+#endif
 
 // split-K epilogue: slices are added in slice order (deterministic), then bias + activation
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(LinArgs a)
