@@ -25,7 +25,7 @@ for _ in range(int(os.environ.get("TRACE_WARM", "400"))):
 torch.cuda.synchronize()
 L = _lib.lib()
 L.reco_debug_gemm_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
-n = min(((M + 127) // 128) * ((N + 127) // 128), 8192)
+n = min(int(os.environ.get("TRACE_WGS", ((M + 127) // 128) * ((N + 127) // 128))), 8192)
 buf = np.zeros(8 * n, dtype=np.uint64)
 assert L.reco_debug_gemm_trace(buf.ctypes.data, 8 * n) == 0
 rec = buf.reshape(n, 8)
