@@ -1,5 +1,7 @@
+#!/usr/bin/env python3
+"""CSR encoder layer against the number of k ranges (XCD placement) for the AutoRec and Hybrid weight sizes: the sweep behind ops.csr_k_ranges (DESIGN section 3 K-c')."""
 import os, sys, time, json
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, "tools"))
 import torch, numpy as np
 from recommender_amd import ops, _lib
 from bench_kernels import _ml1m_like_matrix
