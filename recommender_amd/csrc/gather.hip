@@ -15,6 +15,8 @@
 //   1 x 4096: 1.821 / 0.772    1 x 8192: 1.859 / 0.789    1 x 3072: 2.046 / 0.822    1 x 1024: 2.497 / 0.839    **1 x 2048: 1.800 / 0.767**
 // One float4 per thread with every CU's 32 wave slots filled (8 workgroups of 256 per CU) beats deeper per-thread unrolling: the
 // unrolled loads of a thread lie a whole grid sweep apart and scatter the write stream over as many DRAM pages.
+// Non-temporal LOADS of the table rows (the stores already are) lose: 1.798 -> 1.933 ms fused (an item row is read four times at
+// 4 M pairs over 1 M items and the caches were serving the repeats), gather_rows unchanged.
 #ifndef RECO_GATHER_UNROLL
 #define RECO_GATHER_UNROLL 1
 #endif
