@@ -640,11 +640,28 @@ int launch_linear_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_
     if (s11 >= s12 && s11 >= s21 && s11 >= s22) { bm = 128; bn = 128; }
     else if (s12 >= s21 && s12 >= s22) { bm = 128; bn = 64; }
     else if (s21 >= s22) { bm = 64; bn = 128; }
+    // Two corrections the grid-fill model above cannot see, from forcing every shape on the product's GEMMs (tools/gemm_shape_exp.py,
+    // ms per call at 128x128 / 128x64 / 64x128 / 64x64, table in DESIGN section 3 K-c):
+    //  (a) a large A against a narrow output (the Hybrid user encoder: A = the 89-MB rating matrix, N = 256): every tile column
+    //      re-reads A, so the shapes with the fewest tile columns win -- 0.134 / 0.165 / 0.128 / 0.151;
+    //  (b) a large output behind a short K (the decoders): a tile is mostly prologue and epilogue, and smaller tiles put more of
+    //      them in flight -- K = 500: 0.2225 / 0.2109 / 0.2166 / 0.2191; K = 256: 0.134 / 0.130 / 0.130 / 0.117.
+    const int64_t tiles128 = ceil_div64(M, 128) * ceil_div64(N, 128);
+    if (!at && N <= 256 && M * K * 4 >= (32ll << 20) && bn == 64) {
+        bn = 128;
+        bm = s11 >= s21 ? 128 : 64;
+    } else if (!at && tiles128 > 1024 && K <= 768) {
+        if (K <= 320) { bm = 64; bn = 64; }
+        else { bm = 128; bn = 64; }
+    }
 #ifdef RECO_DIAG_GEMM_TILE         // diagnostic builds only: force the tile shape
     if (const char* e = getenv("RECO_GEMM_TILE")) { bm = atoi(e); const char* x = strchr(e, 'x'); bn = x ? atoi(x + 1) : bm; }
 #endif
     if (ws != nullptr) {
         int sp = choose_splits(ceil_div64(M, bm) * ceil_div64(N, bn), K);
+#ifdef RECO_DIAG_GEMM_TILE         // diagnostic builds only: force the number of K slices
+        if (const char* e = getenv("RECO_GEMM_SPLITS")) sp = atoi(e);
+#endif
         while (sp > 1 && (size_t)sp * M * N * sizeof(float) > ws_bytes) --sp;
         if (sp > 1) {
             a.splits = sp;
