@@ -67,7 +67,6 @@ struct LinArgs {
     int m_fast;              // tile order: 1 = walk the tile grid along m first (linear_kernel)
     const float* out_scale;  // nullable device word: every output is multiplied by it after bias + activation (the tower's layer-1
                              // projections are written pre-scaled by a power of two, tower_shared.h layer1_scale)
-    int64_t half_from;       // >= 0: workgroups from this index on compute N-HALVES of the tiles from this index on (linear_kernel)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float lo, float hi)
@@ -128,20 +127,15 @@ static __device__ unsigned long long g_gemm_trace[8 * 8192];
 #define GEMM_STAMP(i) do { } while (0)
 #endif
 
-// HALF: the workgroup computes one N-half (BM x BN/2) of output tile `tile` -- the four waves stay 2 (M) x 2 (N), a wave's
-// tile is (BM/2) x (BN/4) -- see linear_kernel for when.
-template <int BM, int BN, int VEC, bool AT, bool SPLIT, bool ONE, bool DMAT, bool HALF>
-__device__ __forceinline__ void linear_body(const LinArgs& a, int64_t tile, int nh, int split)
+template <int BM, int BN, int VEC, bool AT, bool SPLIT, bool ONE, bool DMAT>
+__global__ __launch_bounds__(256, DMAT ? (ONE ? 4 : 2) : 1) void linear_kernel(LinArgs a)
 {
     GEMM_STAMP(0);
     static_assert(!DMAT || (!AT && !SPLIT && VEC == 4), "LDS-direct staging: plain exact form with 16-byte aligned rows only");
-    static_assert(!HALF || (BN == 128 && !AT && !SPLIT), "half tiles: plain exact form, 128-wide tiles");
     constexpr bool DMA = DMAT;
     constexpr int LSD = DMA ? BK : LS;          // LDS row stride of the exact form
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int RA = BM / 32, RB = BN / 32;   // float4 per thread per operand per K tile
-    constexpr int TNE = HALF ? TN / 2 : TN, RBE = HALF ? RB / 2 : RB;          // what this workgroup actually computes / stages
-    constexpr int WNS = HALF ? BN / 4 : BN / 2;                                 // columns per wave column
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // layout: [buf][A tile BM*LS | B tile BN*LS] floats;  split form: [buf][piece(3)][A tile BM*LSB | B tile BN*LSB] bf16
     constexpr int BUF = SPLIT ? 3 * (BM + BN) * LSB / 2 : (BM + BN) * LSD;     // in floats
@@ -163,6 +157,8 @@ __device__ __forceinline__ void linear_body(const LinArgs& a, int64_t tile, int 
 
     const int64_t tiles_n = (a.N + BN - 1) / BN;
     const int64_t tiles_m = (a.M + BM - 1) / BM;
+    const int64_t tiles = tiles_n * tiles_m;
+    const int split = (int)(blockIdx.x / tiles);
     // Which output tile this workgroup computes.  Consecutive workgroups go to the 8 XCDs round-robin (speed only, never
     // correctness) and every XCD has its own 4-MB L2.  Walking the tile grid along a dimension whose tile count is a multiple of
     // 8 therefore gives XCD x every eighth operand slab of that dimension -- the same few slabs for the whole launch, L2-resident
@@ -171,9 +167,10 @@ __device__ __forceinline__ void linear_body(const LinArgs& a, int64_t tile, int 
     // n fastest 0.244 ms, m fastest 0.231; the unswapped 29 x 48 form: n fastest 0.230, m fastest 0.243.  Contiguous tile ranges
     // per XCD and Triton-style grouped orders (groups of 2-8 tile rows / columns, with and without the per-XCD ranges) were
     // measured too: each helps one orientation by the same 5 % and costs the other 13-19 %.
+    int64_t tile = blockIdx.x % tiles;
     if (a.m_fast) tile = (tile % tiles_m) * tiles_n + tile / tiles_m;
     const int64_t m0 = (tile / tiles_n) * BM;
-    const int64_t n0 = (tile % tiles_n) * BN + (HALF ? nh * (BN / 2) : 0);
+    const int64_t n0 = (tile % tiles_n) * BN;
     const int64_t kb = split * a.k_per_split;                                   // this block's K slice [kb, ke)
     const int64_t ke = kb + a.k_per_split < a.K ? kb + a.k_per_split : a.K;
 
@@ -199,7 +196,7 @@ __device__ __forceinline__ void linear_body(const LinArgs& a, int64_t tile, int 
         arow[s] = a.A + r * a.lda + kb + 4 * sc;
     }
 #pragma unroll
-    for (int s = 0; s < RBE; ++s) {
+    for (int s = 0; s < RB; ++s) {
         int64_t n = n0 + sr + 32 * s;
         if (n >= a.N) n = a.N - 1;
         wrow[s] = a.W + n * a.ldw + kb + 4 * sc;
@@ -209,7 +206,7 @@ __device__ __forceinline__ void linear_body(const LinArgs& a, int64_t tile, int 
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < TNE; ++tn)
+        for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
@@ -258,7 +255,7 @@ __device__ __forceinline__ void linear_body(const LinArgs& a, int64_t tile, int 
                 for (int s = 0; s < RA; ++s) ra[s] = load_k4<VEC, true>(arow[s], k0, Kl - 4 * sc);
             }
 #pragma unroll
-            for (int s = 0; s < RBE; ++s) rb[s] = load_k4<VEC, true>(wrow[s], k0, Kl - 4 * sc);
+            for (int s = 0; s < RB; ++s) rb[s] = load_k4<VEC, true>(wrow[s], k0, Kl - 4 * sc);
         } else {
             if constexpr (AT) load_a_trans(k0, false);
             else {
@@ -266,7 +263,7 @@ __device__ __forceinline__ void linear_body(const LinArgs& a, int64_t tile, int 
                 for (int s = 0; s < RA; ++s) ra[s] = load_k4<VEC, false>(arow[s], k0, Kl);
             }
 #pragma unroll
-            for (int s = 0; s < RBE; ++s) rb[s] = load_k4<VEC, false>(wrow[s], k0, Kl);
+            for (int s = 0; s < RB; ++s) rb[s] = load_k4<VEC, false>(wrow[s], k0, Kl);
         }
     };
     auto store_tile = [&](int buf) {
@@ -301,7 +298,7 @@ __device__ __forceinline__ void linear_body(const LinArgs& a, int64_t tile, int 
                 for (int s = 0; s < RA; ++s) put4(base + (sr + 32 * s) * LSB + 4 * sc, ra[s]);
             }
 #pragma unroll
-            for (int s = 0; s < RBE; ++s) put4(base + BM * LSB + (sr + 32 * s) * LSB + 4 * sc, rb[s]);
+            for (int s = 0; s < RB; ++s) put4(base + BM * LSB + (sr + 32 * s) * LSB + 4 * sc, rb[s]);
             return;
         }
         float* s_a = smem + buf * BUF;
@@ -328,7 +325,7 @@ __device__ __forceinline__ void linear_body(const LinArgs& a, int64_t tile, int 
             for (int s = 0; s < RA; ++s) *reinterpret_cast<f32x4*>(s_a + (sr + 32 * s) * LSD + 4 * sc_pos) = ra[s];
         }
 #pragma unroll
-        for (int s = 0; s < RBE; ++s) *reinterpret_cast<f32x4*>(s_b + (sr + 32 * s) * LSD + 4 * sc_pos) = rb[s];
+        for (int s = 0; s < RB; ++s) *reinterpret_cast<f32x4*>(s_b + (sr + 32 * s) * LSD + 4 * sc_pos) = rb[s];
     };
     // DMA: tile t into the LDS image; a full tile goes straight from global memory, the ragged last one through registers
     auto stage_dma = [&](int64_t t, int buf, bool wait) {
@@ -343,7 +340,7 @@ __device__ __forceinline__ void linear_body(const LinArgs& a, int64_t tile, int 
             for (int s = 0; s < RA; ++s)
                 __builtin_amdgcn_global_load_lds((gptr_t)(arow[s] + k0), (lptr_t)(smem + buf * BUF + (32 * s + 8 * wave) * BK), 16, 0, 0);
 #pragma unroll
-            for (int s = 0; s < RBE; ++s)
+            for (int s = 0; s < RB; ++s)
                 __builtin_amdgcn_global_load_lds((gptr_t)(wrow[s] + k0), (lptr_t)(smem + buf * BUF + BM * BK + (32 * s + 8 * wave) * BK), 16, 0, 0);
         }
         if (wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -376,7 +373,7 @@ __device__ __forceinline__ void linear_body(const LinArgs& a, int64_t tile, int 
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm) fa[tm][c] = *reinterpret_cast<const bf16x8*>(pa + c * PIECE + tm * 32 * LSB + 16 * ks);
 #pragma unroll
-                    for (int tn = 0; tn < TNE; ++tn) fb[tn][c] = *reinterpret_cast<const bf16x8*>(pb + c * PIECE + tn * 32 * LSB + 16 * ks);
+                    for (int tn = 0; tn < TN; ++tn) fb[tn][c] = *reinterpret_cast<const bf16x8*>(pb + c * PIECE + tn * 32 * LSB + 16 * ks);
                 }
                 // six cross terms, smallest first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
                 constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};
@@ -385,12 +382,12 @@ __device__ __forceinline__ void linear_body(const LinArgs& a, int64_t tile, int 
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                        for (int tn = 0; tn < TNE; ++tn)
+                        for (int tn = 0; tn < TN; ++tn)
                             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][ta[term]], fb[tn][tb[term]], acc[tm][tn], 0, 0, 0);
             }
         } else {
         const float* s_a = smem + (t & (NBUF - 1)) * BUF + (wm * (BM / 2) + i) * LSD + ((DMA || AT) ? 0 : 4 * h);
-        const float* s_b = smem + (t & (NBUF - 1)) * BUF + BM * LSD + (wn * WNS + i) * LSD + (DMA ? 0 : 4 * h);
+        const float* s_b = smem + (t & (NBUF - 1)) * BUF + BM * LSD + (wn * (BN / 2) + i) * LSD + (DMA ? 0 : 4 * h);
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {
             f32x4 fa[TM], fb[TN];
@@ -401,13 +398,13 @@ __device__ __forceinline__ void linear_body(const LinArgs& a, int64_t tile, int 
                 else fa[tm] = *reinterpret_cast<const f32x4*>(s_a + tm * 32 * LSD + fo);
             }
 #pragma unroll
-            for (int tn = 0; tn < TNE; ++tn) fb[tn] = *reinterpret_cast<const f32x4*>(s_b + tn * 32 * LSD + fo);
+            for (int tn = 0; tn < TN; ++tn) fb[tn] = *reinterpret_cast<const f32x4*>(s_b + tn * 32 * LSD + fo);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                    for (int tn = 0; tn < TNE; ++tn)
+                    for (int tn = 0; tn < TN; ++tn)
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm][jj], fb[tn][jj], acc[tm][tn], 0, 0, 0);
         }
         }
@@ -431,8 +428,8 @@ __device__ __forceinline__ void linear_body(const LinArgs& a, int64_t tile, int 
     const bool brows = a.bias && a.bias_rows, bcols = a.bias && !a.bias_rows;
     float bvn[TN];
 #pragma unroll
-    for (int tn = 0; tn < TNE; ++tn) {
-        const int64_t n = n0 + wn * WNS + tn * 32 + i;
+    for (int tn = 0; tn < TN; ++tn) {
+        const int64_t n = n0 + wn * (BN / 2) + tn * 32 + i;
         bvn[tn] = (bcols && n < a.N) ? a.bias[n] : 0.f;
     }
 #pragma unroll
@@ -448,8 +445,8 @@ __device__ __forceinline__ void linear_body(const LinArgs& a, int64_t tile, int 
                 brow[jj] = (brows && m < a.M) ? a.bias[m] : 0.f;
             }
 #pragma unroll
-            for (int tn = 0; tn < TNE; ++tn) {
-                const int64_t n = n0 + wn * WNS + tn * 32 + i;
+            for (int tn = 0; tn < TN; ++tn) {
+                const int64_t n = n0 + wn * (BN / 2) + tn * 32 + i;
                 if (n >= a.N) continue;
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
@@ -470,31 +467,6 @@ __device__ __forceinline__ void linear_body(const LinArgs& a, int64_t tile, int 
     if (threadIdx.x == 0 && blockIdx.x < 8192)
         g_gemm_trace[8 * blockIdx.x + 4] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
 #endif
-}
-
-// Workgroup -> unit of work.  Normally one output tile (and K slice) per workgroup.  The single-buffered LDS-direct form relies on
-// FOUR workgroups sharing a CU (one's staging and stores under the others' MFMAs), and a launch whose tile count is a little over a
-// multiple of the resident set ends with a sparse last round: the AutoRec decoder's 1,392 tiles are 1,024 at once, then 368 --
-// 1.44 per CU, each alone needing 41 us for 26.7 us of MFMAs (workgroup timeline, tools/gemm_trace.py).  The launcher therefore
-// cuts the tiles of such a last round into N-halves (half_from): twice the workgroups at half the work, 2.9 per CU.  Every output
-// is still the one k-ordered chain (nothing is split along K): same bits as before.  Decoder 0.234 -> 0.227 ms (same-box A/B);
-// the last round's K loops go from 85 to ~60 us, the rest of what the timeline shows stays: all four workgroups of a CU finish
-// their K loops together, the epilogues (64 MB of stores at once) and the next round's first tiles have no MFMA work beside
-// them.  Putting half of the half tiles into the FIRST resident set (so that a CU's workgroups would not finish together) does
-// not de-synchronise anything -- the four step through their K tiles in lock-step at the MFMA pipe's pace whatever their widths
-// -- and measured 0.242-0.259 against 0.241-0.244 ms on the same box.
-template <int BM, int BN, int VEC, bool AT, bool SPLIT, bool ONE, bool DMAT>
-__global__ __launch_bounds__(256, DMAT ? (ONE ? 4 : 2) : 1) void linear_kernel(LinArgs a)
-{
-    const int64_t tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM);
-    if constexpr (DMAT && ONE && BN == 128 && !AT && !SPLIT) {
-        if (a.half_from >= 0 && (int64_t)blockIdx.x >= a.half_from) {           // uniform
-            const int64_t u = (int64_t)blockIdx.x - a.half_from;
-            linear_body<BM, BN, VEC, AT, SPLIT, ONE, DMAT, true>(a, a.half_from + (u >> 1), (int)(u & 1), 0);
-            return;
-        }
-    }
-    linear_body<BM, BN, VEC, AT, SPLIT, ONE, DMAT, false>(a, (int64_t)blockIdx.x % tiles, 0, (int)(blockIdx.x / tiles));
 }
 
 #ifdef RECO_DIAG_GEMM_TRACE
@@ -525,11 +497,7 @@ int launch_k(const LinArgs& a, hipStream_t s)
     constexpr size_t lds = SPLIT ? (size_t)3 * (BM + BN) * LSB * 2 : (size_t)((AT || ONE) ? 1 : 2) * (BM + BN) * LS * sizeof(float);
     static bool attr[RECO_MAX_DEVICES] = {};
     if (int rc = reco_allow_lds(reinterpret_cast<const void*>(&linear_kernel<BM, BN, VEC, AT, SPLIT, ONE, DMAT>), lds, attr)) return rc;
-    int64_t blocks = ceil_div64(a.M, BM) * ceil_div64(a.N, BN) * a.splits;
-    if (a.half_from >= 0) {                                  // the tiles from half_from on run as two half-tile workgroups each
-        RECO_REQUIRE(DMAT && ONE && BN == 128 && !AT && !SPLIT && a.splits == 1 && a.half_from <= blocks, "linear: half tiles on a kernel without them");
-        blocks = a.half_from + 2 * (blocks - a.half_from);
-    }
+    const int64_t blocks = ceil_div64(a.M, BM) * ceil_div64(a.N, BN) * a.splits;
     RECO_REQUIRE(blocks < (1ll << 31), "linear grid too large");
     {
         ProfScope prof(s, RECO_PROF_LINEAR);
@@ -626,7 +594,7 @@ int launch_linear_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_
     RECO_REQUIRE(lda >= (at ? M : K) && ldw >= K && ldc >= N, "linear: leading dimension smaller than the row");
     RECO_REQUIRE(!(at && a_rows), "linear: row gather and transposed A cannot be combined");
     LinArgs a{A, lda, a_rows, a_rows ? a_row_limit : M, M, W, ldw, bias, N, K, act, lo, hi, C, ldc, oob, 1, K, nullptr,
-              at ? 1 : 0, (flags & RECO_LINEAR_BIAS_PER_ROW) ? 1 : 0, 0, out_scale, -1};
+              at ? 1 : 0, (flags & RECO_LINEAR_BIAS_PER_ROW) ? 1 : 0, 0, out_scale};
     int vec = 1;
     const bool a4 = at || (lda % 4 == 0 && (uintptr_t)A % 16 == 0), a2 = at || (lda % 2 == 0 && (uintptr_t)A % 8 == 0);
     if (a4 && ldw % 4 == 0 && (uintptr_t)W % 16 == 0) vec = 4;
@@ -677,20 +645,5 @@ int launch_linear_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_
         a.m_fast = (gm != gn) ? (gm ? 1 : 0) : (tm > tn ? 1 : 0);
     }
     if (flags & RECO_LINEAR_SPLIT_BF16X3) return launch_tile<true>(a, bm, bn, vec, s);
-#ifndef RECO_GEMM_NO_HALF_TAIL
-    // a sparse last round of the single-buffered LDS-direct 128 x 128 form runs as half tiles (linear_kernel); the conditions are
-    // launch_v's for that instantiation
-    if (bm == 128 && bn == 128 && vec == 4 && !at && a.splits == 1 && a.k_per_split <= 768 && a.k_per_split >= 12 * BK) {
-        static int n_cu = 0;                              // one GPU model per node: the CU count is the same on every device
-        if (n_cu == 0) {
-            int dev = 0;
-            RECO_CHECK_HIP(hipGetDevice(&dev));
-            RECO_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        }
-        const int64_t tiles = ceil_div64(M, 128) * ceil_div64(N, 128), resident = 4ll * n_cu;
-        const int64_t last = tiles % resident;
-        if (tiles > resident && last > 0 && 2 * last <= resident + resident / 4) a.half_from = tiles - last;
-    }
-#endif
     return launch_tile<false>(a, bm, bn, vec, s);
 }
