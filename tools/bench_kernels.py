@@ -50,13 +50,18 @@ def timed(fn, steps, warmup, dev, launches_per_step_cap=24):
         if n_warm % 8 == 0:
             torch.cuda.synchronize(dev)
     cap = steps * launches_per_step_cap
+    # wall time per step WITHOUT the hook (an event pair costs ~4 us of stream time per launch: 4 % of a 0.4-ms step with four
+    # kernels), then the same steps once more with it for the per-kernel durations
     torch.cuda.synchronize(dev)
-    _lib.check(L.reco_profile_enable(cap))
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
     torch.cuda.synchronize(dev)
     el = time.perf_counter() - t0
+    _lib.check(L.reco_profile_enable(cap))
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize(dev)
     ms = (ctypes.c_float * cap)()
     kinds = (ctypes.c_int32 * cap)()
     n = ctypes.c_int(0)
