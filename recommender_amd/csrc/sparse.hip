@@ -211,7 +211,16 @@ __global__ __launch_bounds__(256) void csr_reduce_kernel(CsrArgs a)
     for (int64_t n = (int64_t)blockIdx.y * 256 + threadIdx.x; n < a.N; n += (int64_t)gridDim.y * 256) {
         float v = 0.f;
         if (s1 > s0) v = a.partial[s0 * a.N + n];
-        for (int64_t s = s0 + 1; s < s1; ++s) v += a.partial[s * a.N + n];
+        // eight partial sums in flight, added in segment order (a popular row has dozens: one dependent load per add was the
+        // launch's tail)
+        for (int64_t s = s0 + 1; s < s1; s += 8) {
+            float p[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] = s + u < s1 ? a.partial[(s + u) * a.N + n] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s + u < s1) v += p[u];                      // uniform per row
+        }
         a.C[row * a.ldc + n] = csr_act(v + (a.bias ? a.bias[n] : 0.f), a.act, a.lo, a.hi);
     }
 }

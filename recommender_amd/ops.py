@@ -190,10 +190,11 @@ class CsrMatrix:
     triplets; the scoring path then never touches the zeros.  `shape` = (rows, cols).
 
     Segment table (include/reco_hip.h, reco_csr_linear_f32): the columns are cut into `k_ranges` ranges that hold equal shares
-    of the nonzeros; a segment is at most SEG_LEN consecutive nonzeros of one row inside one range; `order` places segment
+    of the nonzeros; a segment is at most SEG_LEN (skewed matrices: SEG_LEN_SKEWED) consecutive nonzeros of one row inside one range; `order` places segment
     lists so that workgroup b works in range b % k_ranges (one eighth of the weight matrix per XCD on MI355X).
     """
-    SEG_LEN = 256
+    SEG_LEN = 256            # segment cap while every (row, range) group fits in one segment
+    SEG_LEN_SKEWED = 96      # ... and when some do not (popular items): see _build_segments
     K_RANGES = 8
     SEGS_PER_WG = 4          # RECO_CSR_SEGS_PER_WG
 
@@ -229,6 +230,16 @@ class CsrMatrix:
         nz_row = torch.repeat_interleave(torch.arange(M, **i64), cnt)
         gcnt = torch.bincount(nz_row * R + rng, minlength=M * R)           # nonzeros per (row, range); contiguous in CSR order
         gstart = torch.cumsum(gcnt, 0) - gcnt
+        # A wave walks its segment one nonzero at a time (a weight row per step), so the LONGEST segment bounds the launch and the
+        # segments of a popular row run side by side on different waves.  While every group fits in SEG_LEN nothing is cut (with
+        # one range every row is one segment: no partial sums, no reduce launch, the dense layer's own fmaf chain).  Once some
+        # groups are longer -- item-major rows of a Zipf-popular catalogue: 5,700 raters against 270 on average -- shorter
+        # segments pack better than fewer partial sums save (tools/csr_seg_exp.py, csr + reduce ms at caps 256 / 128 / 96 / 64:
+        # AutoRec encoder 0.150 / 0.127 / 0.125 / 0.125, Hybrid item side 0.115 / 0.098 / 0.096 / 0.099; longer caps lose badly:
+        # 512 0.179 / 0.199, one segment per row 1.05 ms).
+        if self.nnz > 0 and int(gcnt.max()) > SEG:
+            SEG = self.SEG_LEN_SKEWED
+        self.seg_len = SEG
         gsegs = (gcnt + SEG - 1) // SEG                                    # no segment for an empty (row, range)
         gfirst = torch.cumsum(gsegs, 0) - gsegs
         self.n_seg = int(gsegs.sum())

@@ -315,11 +315,15 @@ def test_sparse_linear_over_csr_input(tower_precision):
         Xd = torch.from_numpy(X).cuda(); Wd = torch.from_numpy(W).cuda(); bd = torch.from_numpy(b).cuda()
         csr = ops.CsrMatrix.from_dense(Xd)
         assert csr.nnz == int((X != 0).sum()) and torch.equal(csr.to_dense(), Xd)
-        flat = ops.CsrMatrix.from_dense(Xd, k_ranges=1)      # no k ranges: whole rows, cut only at 256 nonzeros
+        flat = ops.CsrMatrix.from_dense(Xd, k_ranges=1)      # no k ranges: whole rows, cut only at the segment cap
         if dens > 0 and K > ops.CsrMatrix.SEG_LEN:
             assert flat.n_seg > int((X != 0).any(1).sum())   # the full row was cut into segments (an empty row owns none)
+            assert flat.seg_len == ops.CsrMatrix.SEG_LEN_SKEWED      # a row longer than one segment: the short cap (balance)
+        elif dens > 0:
+            assert flat.seg_len == ops.CsrMatrix.SEG_LEN and flat.n_seg == int((X != 0).any(1).sum())     # whole rows
         if dens > 0:
-            assert csr.order is not None and csr.n_seg >= flat.n_seg
+            assert csr.order is not None and (csr.seg_len != flat.seg_len or csr.n_seg >= flat.n_seg)
+            assert csr.n_seg == int(((csr.seg_end - csr.seg_begin) > 0).sum()) and int((csr.seg_end - csr.seg_begin).max()) <= csr.seg_len
             o = csr.order.cpu().numpy()
             assert sorted(o[o >= 0].tolist()) == list(range(csr.n_seg))       # every segment placed exactly once
         Wt = ops.transpose(Wd)
