@@ -20,9 +20,10 @@ g = torch.Generator(device=dev).manual_seed(3)
 cases = [("hybrid user side N=256", False, 256), ("hybrid item side N=256", True, 256), ("autorec item side N=500", True, 500)]
 for seg in [int(x) for x in os.environ.get("SEGS", "256,512,1024,2048,1073741824").split(",")]:
     ops.CsrMatrix.SEG_LEN = seg
+    ops.CsrMatrix.SEG_LEN_SKEWED = min(seg, int(os.environ.get("SKEWED", seg)))
     for name, tr, N in cases:
         K = R.shape[0] if tr else R.shape[1]
-        X = ops.CsrMatrix.from_dense(R, transpose=tr, k_ranges=ops.csr_k_ranges(K, N))
+        X = ops.CsrMatrix.from_dense(R, transpose=tr, k_ranges=int(os.environ["KR"]) if "KR" in os.environ else ops.csr_k_ranges(K, N))
         Wt = torch.randn(K, N, device=dev, generator=g) * 0.05
         b = torch.randn(N, device=dev, generator=g)
         ms, seq = timed(lambda: ops.csr_linear(X, Wt, b, act="relu"), 20, 3, dev)
