@@ -114,8 +114,10 @@ int reco_linear_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_t 
  * val [nnz]; Wt = W^T [K, N] row-major with row stride ldwt (reco_transpose_f32 of the nn.Linear weight, once per weight
  * version).  Zeros contribute nothing to an fp32 sum: a row that is ONE segment is the dense layer's k-ordered fmaf chain without
  * its zero terms, bit for bit; a row cut into several segments sums each on its own and adds the partial sums in segment order
- * (plain adds: another rounding sequence, same fp32 gate).  The segment table cuts the rows into pieces of at most 256
- * consecutive nonzeros, one wave each:
+ * (plain adds: another rounding sequence, same fp32 gate).  The segment table cuts the rows into pieces of consecutive
+ * nonzeros, one wave each; their length is the caller's choice (any length is computed correctly; the Python side uses whole
+ * rows up to 256 nonzeros and pieces of 96 once a row is longer: a wave walks its segment one weight row at a time, so the
+ * longest segment bounds the launch):
  *   row_seg_ptr [M+1] int64   segments of row m are row_seg_ptr[m] .. row_seg_ptr[m+1]-1 (a row without nonzeros has none),
  *   seg_row [S] int32, seg_begin / seg_end [S] int64 (offsets into col / val);
  * a row with one segment is finished in place, the partial sums of the others are added in segment order by a second launch
