@@ -454,6 +454,9 @@ def main_rank(args):
                                    "`cfg5_top100`, same ranks, same protocol",
                        "users_per_gpu": N_USERS, "items": N_ITEMS, "k": K, "weights": "random init, reference ctor order, seed 0, embeddings x25",
                        "precondition_steps": max(args.precondition, 0),
+                       "layer1_projections": "P[u] = W1u eu + b1 and Q[i] = W1i ei are weight-only quantities the handle computes once per weight "
+                                             "version at creation (as forward(user, item) always read them); a step is the tile kernel + the select "
+                                             "(until late in round 3 every step recomputed them for its user range: two 9-us GEMM launches)",
                        "parallelism": parallelism_text(world, args.share_gpus, pipelined, reserve)},
             "roofline": mfma_roofline("tower_tile_kernel<32,true>", pairs_per_rank, tile_ms, n_timed, traffic, traffic_src,
                                       algorithmic_bytes=pairs_per_rank * 4),

@@ -520,10 +520,14 @@ static int score_matrix_impl(reco_tower* t, const int64_t* users, int64_t user_b
     if (!t->mfma)
         return gmf_launch_tile(d.user_gmf, d.item_gmf, d.w_predict, users, cands, user_base, d.n_users, d.n_items, U, N,
                                d.dg, out, ld_out, t->bp, d.act, d.lo, d.hi, oob, s);
-    // layer-1 projections for exactly these users / candidates, inside the call
+    // layer-1 projections for exactly these users / candidates, inside the call -- except where the handle already holds them:
+    // a user RANGE is a row block of the P the handle projected at creation (every output row of that GEMM is its own k-ordered
+    // chain, so a per-call projection of the same rows has the same bits: it was 9 us + a launch gap per step for nothing)
+    const float* Pready = (!users && t->P) ? t->P + user_base * H1 : nullptr;
     const float* urows = users ? d.user_mlp : d.user_mlp + user_base * d.dm;
-    int rc = tower_project(t, urows, users, d.n_users, U, d.item_mlp, cands, d.n_items, Qready ? 0 : N, P, Q, oob, l1, s);
+    int rc = tower_project(t, urows, users, d.n_users, Pready ? 0 : U, d.item_mlp, cands, d.n_items, Qready ? 0 : N, P, Q, oob, l1, s);
     if (rc) return rc;
+    if (Pready) P = const_cast<float*>(Pready);
     if (queue) RECO_CHECK_HIP(hipMemsetAsync(queue, 0, sizeof(unsigned int), s));
     ProfScope prof(s, RECO_PROF_TOWER);
     if (t->img_split)
@@ -566,12 +570,12 @@ extern "C" int reco_tower_score_matrix(reco_tower_t* t, const int64_t* users, in
     }
     const float* l1 = nullptr;
     if ((rc = resolve_l1(t, t->d.user_mlp, t->d.n_users, t->d.item_mlp, t->d.n_items, queue, &l1, (hipStream_t)stream))) return rc;
-    return score_matrix_impl(t, users, user_base, U, cands, N, nullptr, l1, out, ld_out, P, Q, queue, oob, (hipStream_t)stream);
+    const float* Qready = (t->mfma && !cands && N == t->d.n_items && t->Q) ? t->Q : nullptr;       // the whole catalogue: the handle's own projection
+    return score_matrix_impl(t, users, user_base, U, cands, N, Qready, l1, out, ld_out, P, Q, queue, oob, (hipStream_t)stream);
 }
 
 // user-chunk size for the fused score + top-k path
 static const size_t kScoreChunkBytes = (size_t)1 << 30;   // ~1 GiB of score rows per chunk
-static const int64_t kServingUsers = 16;                  // at most this many users: a request, not a batch job
 static const int64_t kTopkExtraRows = 8192;               // bound of rows*splits - rows in topk.hip choose_splits
 
 // leading dimension of the internal score rows: whole 128-byte lines, so that a wave's 32-score store is one line and the
@@ -687,7 +691,7 @@ static int score_topk_fused(reco_tower_t* t, const int64_t* users, int64_t user_
     if (list_room > Uc * fuse_visitors(t->G, Uc, N, k)) list_room = Uc * fuse_visitors(t->G, Uc, N, k);
     if (list_room > Uc * (int64_t)kFuseVisitorsMax) list_room = Uc * (int64_t)kFuseVisitorsMax;
     unsigned long long* partial = reinterpret_cast<unsigned long long*>(w + counter_bytes);
-    const bool cached_q = !cands && N == d.n_items && U <= kServingUsers && t->Q;     // as the unfused form below
+    const bool cached_q = !cands && N == d.n_items && t->Q;     // as the unfused form below
     int rc = RECO_OK;
     const float* l1 = nullptr;
     if ((rc = resolve_l1(t, d.user_mlp, d.n_users, d.item_mlp, d.n_items, static_cast<unsigned int*>(ws), &l1, s))) return rc;
@@ -697,14 +701,16 @@ static int score_topk_fused(reco_tower_t* t, const int64_t* users, int64_t user_
         const int64_t n = U - c0 < Uc ? U - c0 : Uc;
         const int64_t* ul = users ? users + c0 : nullptr;
         const float* urows = ul ? d.user_mlp : d.user_mlp + (user_base + c0) * d.dm;
-        if ((rc = tower_project(t, urows, ul, d.n_users, n, nullptr, nullptr, 0, 0, P, nullptr, oob, l1, s))) return rc;
+        const float* Pc = P;
+        if (!ul && t->P) Pc = t->P + (user_base + c0) * H1;                      // a user range: rows of the handle's own projection
+        else if ((rc = tower_project(t, urows, ul, d.n_users, n, nullptr, nullptr, 0, 0, P, nullptr, oob, l1, s))) return rc;
         // hand-out counters and partial lists start at zero (a list nobody wrote reads as empty)
         int v = fuse_visitors(t->G, n, N, k);                                    // a short last chunk may take more lists per block
         if ((int64_t)v * n > list_room) v = (int)(list_room / n);                // >= kFuseVisitorsMin: the chunk was sized for it
         RECO_CHECK_HIP(hipMemsetAsync(counters, 0, counter_bytes + fused_partial_bytes(n, v, k), s));
         {
             ProfScope prof(s, RECO_PROF_TOWER);
-            rc = tower_launch_tile_topk(t->G, t->has_l3, t->img, P, Q, d.user_gmf, d.item_gmf, ul, cands, user_base + c0, d.n_users,
+            rc = tower_launch_tile_topk(t->G, t->has_l3, t->img, Pc, Q, d.user_gmf, d.item_gmf, ul, cands, user_base + c0, d.n_users,
                                         d.n_items, n, N, t->bp, d.act, d.lo, d.hi, oob, k, v, counters, partial, l1, t->reserve_cus, s);
         }
         if (rc) return rc;
@@ -747,9 +753,9 @@ static int score_topk_impl(reco_tower_t* t, const int64_t* users, int64_t user_b
     const size_t tws_bytes = align_up((size_t)(Uc + kTopkExtraRows) * k * sizeof(uint64_t), 256);
 
     const reco_tower_desc_t& d = t->d;
-    // item-side projection once per call.  Request-sized calls over the whole catalog (a handful of users: the serving
-    // path, inference_engine.py:149-166) reuse the projection of all items that the handle packed at creation instead.
-    const bool cached_q = t->mfma && !cands && N == d.n_items && U <= kServingUsers && t->Q;
+    // item-side projection once per call; calls over the whole catalogue reuse the projection of all items that the handle
+    // packed at creation instead (the serving path, inference_engine.py:149-166, and every full-catalogue batch step).
+    const bool cached_q = t->mfma && !cands && N == d.n_items && t->Q;
     const float* l1 = nullptr;
     if ((rc = resolve_l1(t, d.user_mlp, d.n_users, d.item_mlp, d.n_items, queue, &l1, s))) return rc;
     if (cached_q) Q = t->Q;
