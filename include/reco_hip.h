@@ -246,7 +246,8 @@ int reco_tower_score_rows(reco_tower_t* t, const float* u_gmf, const float* i_gm
 /* Full (user x candidate) score matrix: out[u, n] = score(users[u], cands[n])
  * replaces the per-user loop around model(user_t, item_t)  src/api/core/inference_engine.py:149-164
  * users NULL -> user_base + u;  cands NULL -> n.  out row stride ld_out (floats).
- * Recomputes the layer-1 projections for exactly these users/candidates inside the call. */
+ * Explicit id lists (users / cands given) are projected through layer 1 inside the call; a user RANGE and the whole catalogue
+ * (cands NULL, N = n_items) read the rows the handle projected at creation (same bits: every row is its own k-ordered chain). */
 size_t reco_tower_matrix_workspace_bytes(int64_t U, int64_t N);
 int reco_tower_score_matrix(reco_tower_t* t, const int64_t* users, int64_t user_base, int64_t U,
                             const int64_t* cands, int64_t N, float* out, int64_t ld_out,
