@@ -442,6 +442,31 @@ def test_linear_shapes_and_epilogues(tower_precision):
         assert (err <= 4e-7 * (scale + 1) + 1e-6).all(), (M, N, K, "bias_per_row")
 
 
+def test_cached_projections_equal_per_call_projections_bit_for_bit():
+    """A user RANGE / the whole catalogue read the layer-1 projections the handle computed at creation; explicit id lists are
+    projected inside the call (api.hip score_matrix_impl).  Same users, same items: same bits, in the matrix, the two-kernel
+    top-k and the fused one."""
+    from recommender_amd.helpers import NCF
+    torch.manual_seed(5)
+    m = NCF(700, 900, 32, 3, 0.0, "NeuMF-end").eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "embed" in n:
+                p.mul_(25.0)
+    m = m.cuda()
+    t = m._tower(torch.device("cuda", 0))
+    users = torch.arange(100, 612, device="cuda")
+    items = torch.arange(900, device="cuda")
+    a = t.score_matrix((100, 512))
+    b = t.score_matrix(users, items)
+    c = t.score_matrix((100, 512), items)
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32)) and torch.equal(a.view(torch.int32), c.view(torch.int32))
+    for fused in (False, True):
+        i1, v1 = t.score_topk((100, 512), 10, fused=fused)
+        i2, v2 = t.score_topk(users, 10, items, fused=fused)
+        assert torch.equal(i1, i2) and torch.equal(v1.view(torch.int32), v2.view(torch.int32)), fused
+
+
 def test_linear_tile_shape_never_changes_a_bit():
     """The launcher picks the tile shape from the problem's size (gemm.hip: grid fill, operand re-reads, short-K rule), so the SAME
     rows come out of differently tiled launches depending on how many are asked for.  Without split-K every output is one
