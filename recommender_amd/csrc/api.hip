@@ -16,8 +16,9 @@ int tower_launch_tile(int G, int has_l3, const float* img, const float* P, const
                       int64_t user_base, int64_t n_users, int64_t n_items, int64_t U, int64_t N,
                       float* out, int64_t ld_out, float bp, int act, float lo, float hi, int32_t* oob,
                       unsigned int* next_tile, const float* l1, int reserve_cus, hipStream_t s);
-int tower_launch_l1scale(const float* W1, const float* b1, int dm, const float* u_rows, int64_t u_elems,
-                         const float* i_rows, int64_t i_elems, unsigned int* scratch, float* out, hipStream_t s);
+int tower_launch_l1norms(const float* W1, const float* b1, int dm, float* norms, hipStream_t s);
+int tower_launch_l1scale(const float* norms, const float* u_rows, int64_t u_elems, const float* i_rows, int64_t i_elems,
+                         unsigned int* scratch, float* out, hipStream_t s);
 int tower_launch_scale_compare(const float* stored, const float* fresh, int32_t* stale, hipStream_t s);
 int tower_launch_pairs(int G, int has_l3, const float* img, const float* P, const float* Q,
                        const float* EUg, const float* EIg, const int64_t* user, const int64_t* item,
@@ -254,12 +255,13 @@ struct reco_tower {
     float* Q;         // [n_items,128] layer-1 item projection
     float* l1;        // device words {s, 1/s}: the power of two layer 1 is scaled by (tower_shared.h), fixed by the handle's tables;
                       // null in split mode and for handles without tables (then per call, resolve_l1)
+    float* l1n;       // [3 H1] layer-1 weight norms behind that scale (tower.hip l1norms_kernel); null in split mode and without an MLP branch
     int device;
     int reserve_cus;  // CUs the persistent tile kernels leave without a workgroup (reco_tower_set_reserved_cus); 0 = none
 };
 
-// Layer-1 scale words {s, 1/s} (tower_shared.h).  Inside a 256-byte block: floats at words kL1Word, kL1Word + 1, two scratch
-// words for the maxima behind them.  The handle owns such a block when it has tables; calls over row blocks handed in per call
+// Layer-1 scale words {s, 1/s} (tower_shared.h).  Inside a 256-byte block: floats at words kL1Word, kL1Word + 1, three scratch
+// words (two maxima, one ticket) behind them.  The handle owns such a block when it has tables; calls over row blocks handed in per call
 // compute theirs into the head of the call workspace (word 0 of that head is the tile work-queue counter).
 static const int kL1Word = 16, kL1ScratchWord = 20, kL1CheckScratchWord = 24, kL1CheckWord = 28;
 
@@ -311,6 +313,7 @@ extern "C" void reco_tower_destroy(reco_tower_t* t)
     (void)hipFree(t->P);
     (void)hipFree(t->Q);
     (void)hipFree(t->l1);
+    (void)hipFree(t->l1n);
     delete t;
 }
 
@@ -371,6 +374,7 @@ extern "C" int reco_tower_create(const reco_tower_desc_t* d, void* stream, reco_
     if (e == hipSuccess && t->mfma && tables) e = hipMalloc(&t->P, (size_t)d->n_users * H1 * sizeof(float));
     if (e == hipSuccess && t->mfma && tables) e = hipMalloc(&t->Q, (size_t)d->n_items * H1 * sizeof(float));
     if (e == hipSuccess && t->mfma && tables && !split) e = hipMalloc(&t->l1, 256);
+    if (e == hipSuccess && t->mfma && !split) e = hipMalloc(&t->l1n, 3 * H1 * sizeof(float));
     if (e == hipSuccess) e = hipMemcpyAsync(&t->bp, d->b_predict, sizeof(float), hipMemcpyDeviceToHost, s);
     if (e != hipSuccess) {
         reco_set_error("tower_create: %s", hipGetErrorString(e));
@@ -383,8 +387,9 @@ extern "C" int reco_tower_create(const reco_tower_desc_t* d, void* stream, reco_
         if (!rc && t->img1) rc = tower_pack_rows_image(d->W[0], d->b[0], t->img1, s);
         if (!rc && split)
             rc = tower_pack_split_image(d->W[1], t->has_l3 ? d->W[2] : nullptr, t->has_l3, t->img, t->img_split, s);
+        if (!rc && t->l1n) rc = tower_launch_l1norms(d->W[0], d->b[0], d->dm, t->l1n, s);
         if (!rc && tables && t->l1)       // the layer-1 scale of every pair these tables can form, before anything is projected
-            rc = tower_launch_l1scale(d->W[0], d->b[0], d->dm, d->user_mlp, d->n_users * d->dm, d->item_mlp, d->n_items * d->dm,
+            rc = tower_launch_l1scale(t->l1n, d->user_mlp, d->n_users * d->dm, d->item_mlp, d->n_items * d->dm,
                                       reinterpret_cast<unsigned int*>(t->l1) + kL1ScratchWord, t->l1, s);
         if (!rc && tables)
             rc = tower_project(t, d->user_mlp, nullptr, 0, d->n_users, d->item_mlp, nullptr, 0, d->n_items, t->P, t->Q, nullptr, t->l1, s);
@@ -411,7 +416,7 @@ extern "C" int reco_tower_check_scale(reco_tower_t* t, int32_t* stale, void* str
     const reco_tower_desc_t& d = t->d;
     unsigned int* blk = reinterpret_cast<unsigned int*>(t->l1);
     float* fresh = reinterpret_cast<float*>(blk + kL1CheckWord);
-    if (int rc = tower_launch_l1scale(d.W[0], d.b[0], d.dm, d.user_mlp, d.n_users * d.dm, d.item_mlp, d.n_items * d.dm,
+    if (int rc = tower_launch_l1scale(t->l1n, d.user_mlp, d.n_users * d.dm, d.item_mlp, d.n_items * d.dm,
                                       blk + kL1CheckScratchWord, fresh, s)) return rc;
     return tower_launch_scale_compare(t->l1 + 0, fresh, stale, s);
 }
@@ -451,7 +456,7 @@ static int resolve_l1(const reco_tower* t, const float* u_rows, int64_t U, const
     RECO_REQUIRE(head, "internal: no workspace head for the layer-1 scale");
     float* out = reinterpret_cast<float*>(head + kL1Word);
     *l1 = out;
-    return tower_launch_l1scale(t->d.W[0], t->d.b[0], t->d.dm, u_rows, U * t->d.dm, i_rows, N * t->d.dm, head + kL1ScratchWord, out, s);
+    return tower_launch_l1scale(t->l1n, u_rows, U * t->d.dm, i_rows, N * t->d.dm, head + kL1ScratchWord, out, s);
 }
 
 extern "C" size_t reco_tower_rows_workspace_bytes(int64_t B)

@@ -860,45 +860,75 @@ __global__ __launch_bounds__(256) void gmf_tile_kernel(GmfTileArgs a)
     }
 }
 
-// largest finite |element| of x[0, n) into *out (a float's bit pattern; the caller zeroes it)
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t n, unsigned int* out)
+// Layer-1 weight norms, once per handle: norms[f] = |W1u_f|_1, norms[H1 + f] = |W1i_f|_1, norms[2 H1 + f] = |b1_f|
+// (W1 [H1, 2 dm] row-major, user half first; thread f owns output feature f).
+__global__ __launch_bounds__(H1) void l1norms_kernel(const float* __restrict__ W1, const float* __restrict__ b1, int dm, float* norms)
 {
-    float m = 0.f;
-    const int64_t n4 = n / 4;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float av = fabsf(v[c]);
-            if (av > m && av < __builtin_inff()) m = av;
-        }
-    }
-    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float av = fabsf(x[i]);
-        if (av > m && av < __builtin_inff()) m = av;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
-}
-
-// {s, 1/s} from the bound  max_f (|W1u_f|_1 mu + |b1_f|) + max_f |W1i_f|_1 mi  on p + q (tower_shared.h).  One block of H1 threads:
-// thread f owns output feature f of layer 1 (W1 [H1, 2 dm] row-major, user half first).
-__global__ __launch_bounds__(H1) void l1scale_kernel(const float* __restrict__ W1, const float* __restrict__ b1, int dm,
-                                                      const unsigned int* maxima, float* out)
-{
-    __shared__ float s_a[H1], s_c[H1];
     const int f = threadIdx.x;
-    const float mu = __uint_as_float(maxima[0]), mi = __uint_as_float(maxima[1]);
     float lu = 0.f, li = 0.f;
     for (int k = 0; k < dm; ++k) { lu += fabsf(W1[(int64_t)f * 2 * dm + k]); li += fabsf(W1[(int64_t)f * 2 * dm + dm + k]); }
-    const float a = lu * mu + fabsf(b1[f]), c = li * mi;
-    s_a[f] = (a == a && a < __builtin_inff()) ? a : 0.f;
-    s_c[f] = (c == c && c < __builtin_inff()) ? c : 0.f;
+    norms[f] = lu;
+    norms[H1 + f] = li;
+    norms[2 * H1 + f] = fabsf(b1[f]);
+}
+
+// {s, 1/s} from the bound  max_f (|W1u_f|_1 mu + |b1_f|) + max_f |W1i_f|_1 mi  on p + q (tower_shared.h), mu / mi = the largest finite
+// |element| of the user / item rows.  ONE launch (it runs per call for the Hybrid head, whose rows are that call's latents):
+// workgroups [0, gu) scan the user rows, the rest the item rows, each folds its maximum into scratch[0] / scratch[1] (a float's
+// bit pattern) with one atomic per wave; the workgroup that draws the last ticket (scratch[2]) reads both maxima back and writes
+// the scale.  scratch[0..2] are zeroed by the launcher.  Only atomics carry data between workgroups.
+__global__ __launch_bounds__(256) void l1scale_kernel(const float* __restrict__ u_rows, int64_t u_elems, const float* __restrict__ i_rows,
+                                                      int64_t i_elems, unsigned gu, unsigned gi, const float* __restrict__ norms,
+                                                      unsigned int* scratch, float* out)
+{
+    __shared__ unsigned s_ticket;
+    __shared__ float s_red[2][2];
+    const int tid = threadIdx.x;
+    const bool user_side = blockIdx.x < gu;
+    const unsigned b = user_side ? blockIdx.x : blockIdx.x - gu, g = user_side ? gu : gi;
+    if (b < g) {
+        const float* x = user_side ? u_rows : i_rows;
+        const int64_t n = user_side ? u_elems : i_elems;
+        float m = 0.f;
+        const int64_t n4 = n / 4;
+        for (int64_t i = (int64_t)b * 256 + tid; i < n4; i += (int64_t)g * 256) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float av = fabsf(v[c]);
+                if (av > m && av < __builtin_inff()) m = av;
+            }
+        }
+        for (int64_t i = n4 * 4 + (int64_t)b * 256 + tid; i < n; i += (int64_t)g * 256) {
+            const float av = fabsf(x[i]);
+            if (av > m && av < __builtin_inff()) m = av;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((tid & 63) == 0 && m > 0.f) atomicMax(scratch + (user_side ? 0 : 1), __float_as_uint(m));
+    }
+    __threadfence();
+    __syncthreads();                                           // every wave's maximum is out before the ticket is drawn
+    if (tid == 0) s_ticket = atomicAdd(scratch + 2, 1u);
     __syncthreads();
-    if (f == 0) {
-        float ma = 0.f, mc = 0.f;
-        for (int i = 0; i < H1; ++i) { ma = fmaxf(ma, s_a[i]); mc = fmaxf(mc, s_c[i]); }
+    if (s_ticket != gridDim.x - 1) return;                     // workgroup-uniform
+    __threadfence();
+    float a = 0.f, c = 0.f;
+    if (tid < H1) {
+        const float mu = __uint_as_float(__hip_atomic_load(scratch + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const float mi = __uint_as_float(__hip_atomic_load(scratch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        a = norms[tid] * mu + norms[2 * H1 + tid];
+        c = norms[H1 + tid] * mi;
+        a = (a == a && a < __builtin_inff()) ? a : 0.f;
+        c = (c == c && c < __builtin_inff()) ? c : 0.f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a = fmaxf(a, __shfl_xor(a, o)); c = fmaxf(c, __shfl_xor(c, o)); }
+    static_assert(H1 == 128, "two waves hold the H1 features");
+    if ((tid & 63) == 0 && tid < H1) { s_red[tid >> 6][0] = a; s_red[tid >> 6][1] = c; }
+    __syncthreads();
+    if (tid == 0) {
+        const float ma = fmaxf(s_red[0][0], s_red[1][0]), mc = fmaxf(s_red[0][1], s_red[1][1]);
         const Layer1Scale sc = layer1_scale_for((ma + mc) * 1.001f);      // margin for the roundings of this estimate
         out[0] = sc.s;
         out[1] = sc.inv;
@@ -1080,22 +1110,27 @@ int gmf_launch_tile(const float* EUg, const float* EIg, const float* wp, const i
     return RECO_OK;
 }
 
-// out[0..1] = {s, 1/s} for layer 1 over the given user / item rows (tower_shared.h); scratch: 2 words, cleared here.
-// Three small launches on `s`; nothing is read back.
-int tower_launch_l1scale(const float* W1, const float* b1, int dm, const float* u_rows, int64_t u_elems,
-                         const float* i_rows, int64_t i_elems, unsigned int* scratch, float* out, hipStream_t s)
+int tower_launch_l1norms(const float* W1, const float* b1, int dm, float* norms, hipStream_t s)
 {
-    RECO_CHECK_HIP(hipMemsetAsync(scratch, 0, 2 * sizeof(unsigned int), s));
-    const int64_t elems[2] = {u_elems, i_elems};
-    const float* rows[2] = {u_rows, i_rows};
-    for (int side = 0; side < 2; ++side) {
-        if (elems[side] <= 0) continue;
-        const int64_t blocks = ceil_div64(elems[side], 256 * 16);
-        hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, s, rows[side], elems[side],
-                           scratch + side);
-        RECO_CHECK_LAUNCH();
-    }
-    hipLaunchKernelGGL(l1scale_kernel, dim3(1), dim3(H1), 0, s, W1, b1, dm, scratch, out);
+    hipLaunchKernelGGL(l1norms_kernel, dim3(1), dim3(H1), 0, s, W1, b1, dm, norms);
+    RECO_CHECK_LAUNCH();
+    return RECO_OK;
+}
+
+// out[0..1] = {s, 1/s} for layer 1 over the given user / item rows (tower_shared.h); norms: tower_launch_l1norms of the handle's
+// layer 1; scratch: 3 words, cleared here.  One memset node and one launch on `s`; nothing is read back.
+int tower_launch_l1scale(const float* norms, const float* u_rows, int64_t u_elems, const float* i_rows, int64_t i_elems,
+                         unsigned int* scratch, float* out, hipStream_t s)
+{
+    RECO_CHECK_HIP(hipMemsetAsync(scratch, 0, 3 * sizeof(unsigned int), s));
+    auto side_blocks = [](int64_t elems) -> unsigned {
+        if (elems <= 0) return 0u;
+        const int64_t blocks = ceil_div64(elems, 256 * 16);
+        return (unsigned)(blocks < 512 ? blocks : 512);
+    };
+    const unsigned gu = side_blocks(u_elems), gi = side_blocks(i_elems);
+    const unsigned grid = gu + gi > 0 ? gu + gi : 1u;
+    hipLaunchKernelGGL(l1scale_kernel, dim3(grid), dim3(256), 0, s, u_rows, u_elems, i_rows, i_elems, gu, gi, norms, scratch, out);
     RECO_CHECK_LAUNCH();
     return RECO_OK;
 }
