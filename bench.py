@@ -300,6 +300,10 @@ def mfma_roofline(kernel, pairs_per_launch, kernel_ms, launches, traffic=None, t
 def parallelism_text(world, share_gpus, pipelined, reserve):
     """What the ranks actually do with the top-k lists, in words (config.parallelism)."""
     if world == 1:
+        from recommender_amd.dist import force_collective_setting
+        if force_collective_setting() and dist.is_initialized():
+            return ("one rank, REHEARSAL of the RCCL leg (RECO_FORCE_GATHER=1): the pipelined all-gather of packed top-k is issued "
+                    "in a one-rank group, every step")
         return "one rank: all users on this GPU, no collective is issued (user-sharded with replicated tables at N > 1)"
     backend = "gloo (REHEARSAL: ranks share GPUs, numbers meaningless)" if share_gpus else "RCCL"
     if not pipelined:

@@ -12,7 +12,9 @@ of LDS on every CU, so without a reservation RCCL's kernel starts in the gap bet
 projection / select kernels) and a tile launch that finds a CU still busy simply starts that workgroup later -- tiles come from
 a work queue.  `reserve_cus` (or RECO_RESERVE_CUS) keeps that many CUs free of tile workgroups so the gather can run under a
 tile launch; it costs reserve/256 of the scoring throughput and is off by default.
-With ONE rank the lists are already complete: no collective is issued at all.
+With ONE rank the lists are already complete: no collective is issued at all -- unless `force_collective` (or RECO_FORCE_GATHER=1)
+asks for it: a one-rank RCCL group then runs the very same enqueue / wait / unpack code as N ranks, which is how the RCCL leg is
+exercised on a one-GPU box (tests/test_gpu_dist.py; RCCL refuses two ranks on one device).
 
 Ordering of the collective behind the kernels that produce its input ("the round-1 hang"):
 RCCL ("nccl") launches the collective as a kernel on its own stream behind an event recorded on the caller's stream, so
@@ -48,6 +50,13 @@ def reserved_cus_setting(value=None):
     if not 0 <= r <= 128:
         raise ValueError("reserve_cus must be within [0, 128], got %d" % r)
     return r
+
+
+def force_collective_setting(value=None):
+    """Issue the all-gather even in a one-rank group: the argument, else RECO_FORCE_GATHER (rehearsal / test switch)."""
+    if value is None:
+        value = os.environ.get("RECO_FORCE_GATHER", "0") not in ("", "0")
+    return bool(value)
 
 
 def _stream_ordered(group=None):
@@ -118,13 +127,13 @@ def _unpack(gathered, counts, k):
     return ids, vals.contiguous().view(torch.float32)
 
 
-def all_gather_topk(ids, vals, counts=None, group=None):
+def all_gather_topk(ids, vals, counts=None, group=None, force_collective=None):
     """Concatenate per-rank (ids [u_r,k], vals [u_r,k]) into ([U,k], [U,k]) on every rank with one collective.
 
     counts: list of per-rank row counts (needed when they differ: ranks pad to the maximum and the padding is dropped
     after the gather).  ids / vals that are the two halves of packed_topk_buffers() are sent in place.
     """
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force_collective_setting(force_collective)):
         return ids, vals                           # one rank: the concatenation of one shard is that shard
     world = dist.get_world_size(group)
     k = ids.shape[1]
@@ -181,10 +190,11 @@ class TopkGather:
     watchdog (RCCL): see the module docstring.
     """
 
-    def __init__(self, model, k, total_users=None, candidates=None, group=None, reserve_cus=None):
+    def __init__(self, model, k, total_users=None, candidates=None, group=None, reserve_cus=None, force_collective=None):
         self.k, self.candidates, self.group = k, candidates, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.on = self.world > 1                       # one rank: nothing to gather, no collective is issued
+        # one rank: nothing to gather, no collective is issued (force_collective: module docstring)
+        self.on = self.world > 1 or (dist.is_initialized() and force_collective_setting(force_collective))
         self.ordered = _stream_ordered(group)
         self.rank = dist.get_rank(group) if self.on else 0
         self.device = model._compute_device()
