@@ -181,17 +181,23 @@ class TopkGather:
             done = pipe.step()          # result of the PREVIOUS step (None on the first call), already gathered
         last = pipe.flush()             # result of the last step
 
-    step() enqueues this rank's scoring + top-k into one of two packed buffers and starts the all-gather of that buffer
+    step() enqueues this rank's scoring + top-k into one of `depth` packed buffers and starts the all-gather of that buffer
     asynchronously; the gather overlaps the next step's kernels.  Results are (ids [U,k], scores [U,k]) in user order.
     A result aliases a pipeline buffer and stays valid only until the NEXT step() call, which scores (and gathers) into
     that same buffer: copy what must live longer.
+    depth (or RECO_GATHER_DEPTH, default 2) = buffers in flight: step i returns the result of step i - (depth - 1).  With 2 the
+    compute stream waits for gather i - 1 right behind step i's kernels -- a gather that only found free CUs when tile launch i
+    ended then holds up tile launch i + 1; with 3 the awaited gather is a whole step older and the wait never bites.
     Without an initialised process group it degenerates to the local call.
     A gather that does not complete raises GatherTimeout (non-RCCL backends) or is ended by the process group's
     watchdog (RCCL): see the module docstring.
     """
 
-    def __init__(self, model, k, total_users=None, candidates=None, group=None, reserve_cus=None, force_collective=None):
+    def __init__(self, model, k, total_users=None, candidates=None, group=None, reserve_cus=None, force_collective=None, depth=None):
         self.k, self.candidates, self.group = k, candidates, group
+        self.depth = int(os.environ.get("RECO_GATHER_DEPTH", "2") if depth is None else depth)
+        if not 2 <= self.depth <= 8:
+            raise ValueError("depth must be within [2, 8], got %d" % self.depth)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # one rank: nothing to gather, no collective is issued (force_collective: module docstring)
         self.on = self.world > 1 or (dist.is_initialized() and force_collective_setting(force_collective))
@@ -210,7 +216,7 @@ class TopkGather:
         n_items = self.tower.n_items if candidates is None else len(candidates)
         self.ws = self.tower.topk_workspace(self.count, n_items, k)
         self.slots = []
-        for _ in range(2):
+        for _ in range(self.depth):
             buf, ids, vals = packed_topk_buffers(mx, k, self.device)
             if self.count < mx:
                 buf.zero_()
@@ -222,7 +228,7 @@ class TopkGather:
             self.slots.append({"buf": buf, "ids": ids[:self.count], "vals": vals[:self.count], "gathered": gathered, "work": None,
                                "host_in": host_in, "host_out": host_out})
         self.i = 0
-        self.pending = None
+        self.pending = []                              # slots whose step has been enqueued and not handed out yet, oldest first
 
     def _collect(self, slot):
         if not self.on:
@@ -234,7 +240,7 @@ class TopkGather:
         return _unpack(slot["gathered"].view(self.world, 2, -1, self.k), self.counts, self.k)
 
     def step(self):
-        slot = self.slots[self.i & 1]
+        slot = self.slots[self.i % self.depth]
         self.i += 1
         self.tower.score_topk((self.start, self.count), self.k, self.candidates, None, check_ids=False, ws=self.ws,
                               out=(slot["ids"], slot["vals"]))
@@ -246,11 +252,12 @@ class TopkGather:
                 if not self.ordered:
                     _finish_producer(slot["buf"])
                 slot["work"] = dist.all_gather_into_tensor(slot["gathered"], slot["buf"], group=self.group, async_op=True)
-        done = self._collect(self.pending) if self.pending is not None else None
-        self.pending = slot
-        return done
+        self.pending.append(slot)
+        return self._collect(self.pending.pop(0)) if len(self.pending) >= self.depth else None
 
     def flush(self):
-        done = self._collect(self.pending) if self.pending is not None else None
-        self.pending = None
+        """Result of the LAST step (older ones still in flight are completed and dropped; step() hands them out one at a time)."""
+        done = None
+        while self.pending:
+            done = self._collect(self.pending.pop(0))
         return done
