@@ -75,6 +75,19 @@ def _pipe_worker(rank, world, port, total, k, q):
         for step, (ids, vals) in enumerate(got[1:]):
             ok = ok and torch.equal(ids, (u * 7 + torch.arange(k).view(1, -1) + step).to(torch.int32))
             ok = ok and torch.equal(vals, (u * 0.5 - torch.arange(k).view(1, -1) - step).to(torch.float32))
+        # three buffers in flight: step i hands out step i - 2, flush() the last one; the stub's step counter keeps running
+        deep = TopkGather(_StubModel(_StubTower(total, 50)), k, total, depth=3)
+        got3 = [deep.step() for _ in range(5)]
+        ok = ok and got3[0] is None and got3[1] is None and deep.depth == 3
+        for step, (ids, vals) in enumerate(got3[2:]):
+            ok = ok and torch.equal(ids, (u * 7 + torch.arange(k).view(1, -1) + step).to(torch.int32))
+        ids, vals = deep.flush()
+        ok = ok and torch.equal(ids, (u * 7 + torch.arange(k).view(1, -1) + 4).to(torch.int32)) and deep.flush() is None
+        try:
+            TopkGather(_StubModel(_StubTower(total, 50)), k, total, depth=1)
+            ok = False
+        except ValueError:
+            pass
         q.put((rank, bool(ok), tuple(got[-1][0].shape)))
     finally:
         dist.destroy_process_group()
@@ -170,6 +183,12 @@ def _single_rank_worker(rank, world, port, total, k, q):
         ids = torch.arange(total * k, dtype=torch.int32).view(total, k)
         gi, gv = all_gather_topk(ids, ids.float())
         ok = ok and gi is ids and not calls
+        # forced (the rehearsal switch of the RCCL leg): the same one-rank group now issues the collective, results unchanged
+        gi, gv = all_gather_topk(ids, ids.float(), force_collective=True)
+        ok = ok and len(calls) == 1 and gi is not ids and torch.equal(gi, ids) and torch.equal(gv, ids.float())
+        forced = TopkGather(_StubModel(_ReservingTower(total, 50)), k, total, force_collective=True)
+        got = [forced.step() for _ in range(3)] + [forced.flush()]
+        ok = ok and forced.on and len(calls) == 4 and tuple(got[-1][0].shape) == (total, k)
         q.put((rank, bool(ok), tuple(got[-1][0].shape)))
     finally:
         dist.destroy_process_group()
