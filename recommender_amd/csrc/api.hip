@@ -18,7 +18,7 @@ int tower_launch_tile(int G, int has_l3, const float* img, const float* P, const
                       unsigned int* next_tile, const float* l1, int reserve_cus, hipStream_t s);
 int tower_launch_l1norms(const float* W1, const float* b1, int dm, float* norms, hipStream_t s);
 int tower_launch_l1scale(const float* norms, const float* u_rows, int64_t u_elems, const float* i_rows, int64_t i_elems,
-                         unsigned int* scratch, float* out, hipStream_t s);
+                         unsigned int* scratch, float* out, void* clear, size_t clear_bytes, hipStream_t s);
 int tower_launch_scale_compare(const float* stored, const float* fresh, int32_t* stale, hipStream_t s);
 int tower_launch_pairs(int G, int has_l3, const float* img, const float* P, const float* Q,
                        const float* EUg, const float* EIg, const int64_t* user, const int64_t* item,
@@ -390,7 +390,8 @@ extern "C" int reco_tower_create(const reco_tower_desc_t* d, void* stream, reco_
         if (!rc && t->l1n) rc = tower_launch_l1norms(d->W[0], d->b[0], d->dm, t->l1n, s);
         if (!rc && tables && t->l1)       // the layer-1 scale of every pair these tables can form, before anything is projected
             rc = tower_launch_l1scale(t->l1n, d->user_mlp, d->n_users * d->dm, d->item_mlp, d->n_items * d->dm,
-                                      reinterpret_cast<unsigned int*>(t->l1) + kL1ScratchWord, t->l1, s);
+                                      reinterpret_cast<unsigned int*>(t->l1) + kL1ScratchWord, t->l1,
+                                      reinterpret_cast<unsigned int*>(t->l1) + kL1ScratchWord, 3 * sizeof(unsigned int), s);
         if (!rc && tables)
             rc = tower_project(t, d->user_mlp, nullptr, 0, d->n_users, d->item_mlp, nullptr, 0, d->n_items, t->P, t->Q, nullptr, t->l1, s);
     }
@@ -417,7 +418,7 @@ extern "C" int reco_tower_check_scale(reco_tower_t* t, int32_t* stale, void* str
     unsigned int* blk = reinterpret_cast<unsigned int*>(t->l1);
     float* fresh = reinterpret_cast<float*>(blk + kL1CheckWord);
     if (int rc = tower_launch_l1scale(t->l1n, d.user_mlp, d.n_users * d.dm, d.item_mlp, d.n_items * d.dm,
-                                      blk + kL1CheckScratchWord, fresh, s)) return rc;
+                                      blk + kL1CheckScratchWord, fresh, blk + kL1CheckScratchWord, 3 * sizeof(unsigned int), s)) return rc;
     return tower_launch_scale_compare(t->l1 + 0, fresh, stale, s);
 }
 
@@ -446,17 +447,22 @@ extern "C" int reco_tower_score_pairs(reco_tower_t* t, const int64_t* user, cons
     return run_pairs(t, t->P, t->Q, d.user_gmf, d.item_gmf, user, item, d.n_users, d.n_items, B, out, oob, t->l1, s);
 }
 
-// the scale for a call: the handle's own, or -- a handle without tables -- computed over the row blocks of this call into `head`
+// the scale for a call: the handle's own, or -- a handle without tables -- computed over the row blocks of this call into `head`.
+// *head_cleared: the launch zeroed the whole head first, the tile work-queue counter (word 0) included, so the first tile launch
+// of the call needs no memset of its own.
 static int resolve_l1(const reco_tower* t, const float* u_rows, int64_t U, const float* i_rows, int64_t N, unsigned int* head,
-                      const float** l1, hipStream_t s)
+                      const float** l1, bool* head_cleared, hipStream_t s)
 {
     *l1 = nullptr;
+    *head_cleared = false;
     if (!t->mfma || t->img_split) return RECO_OK;        // GMF-only models have no layer 1; the split mode runs unscaled
     if (t->l1) { *l1 = t->l1; return RECO_OK; }
     RECO_REQUIRE(head, "internal: no workspace head for the layer-1 scale");
     float* out = reinterpret_cast<float*>(head + kL1Word);
     *l1 = out;
-    return tower_launch_l1scale(t->l1n, u_rows, U * t->d.dm, i_rows, N * t->d.dm, head + kL1ScratchWord, out, s);
+    *head_cleared = true;
+    // the whole 256-byte head in one fill (a length that is not a multiple of 16 bytes costs the runtime a second fill kernel)
+    return tower_launch_l1scale(t->l1n, u_rows, U * t->d.dm, i_rows, N * t->d.dm, head + kL1ScratchWord, out, head, 256, s);
 }
 
 extern "C" size_t reco_tower_rows_workspace_bytes(int64_t B)
@@ -512,14 +518,15 @@ extern "C" int reco_tower_score_rows(reco_tower_t* t, const float* u_gmf, const 
 // ---- matrix / top-k forms ----------------------------------------------------------------------
 // Head of every call workspace (256 bytes): word 0 = tile work-queue counter (cleared per launch); words kL1Word.. = the
 // call's layer-1 scale when the handle has none of its own (resolve_l1).
-static const size_t kQueueBytes = 256;
+static const size_t kQueueBytes = 256;       // resolve_l1 clears exactly this much
 static size_t proj_bytes(int64_t rows) { return align_up((size_t)(rows > 0 ? rows : 0) * H1 * sizeof(float), 256); }
 
 extern "C" size_t reco_tower_matrix_workspace_bytes(int64_t U, int64_t N) { return kQueueBytes + proj_bytes(U) + proj_bytes(N); }
 
 static int score_matrix_impl(reco_tower* t, const int64_t* users, int64_t user_base, int64_t U,
                              const int64_t* cands, int64_t N, const float* Qready, const float* l1,
-                             float* out, int64_t ld_out, float* P, float* Q, unsigned int* queue, int32_t* oob, hipStream_t s)
+                             float* out, int64_t ld_out, float* P, float* Q, unsigned int* queue, bool queue_clean, int32_t* oob,
+                             hipStream_t s)
 {
     const reco_tower_desc_t& d = t->d;
     if (!t->mfma)
@@ -533,7 +540,7 @@ static int score_matrix_impl(reco_tower* t, const int64_t* users, int64_t user_b
     int rc = tower_project(t, urows, users, d.n_users, Pready ? 0 : U, d.item_mlp, cands, d.n_items, Qready ? 0 : N, P, Q, oob, l1, s);
     if (rc) return rc;
     if (Pready) P = const_cast<float*>(Pready);
-    if (queue) RECO_CHECK_HIP(hipMemsetAsync(queue, 0, sizeof(unsigned int), s));
+    if (queue && !queue_clean) RECO_CHECK_HIP(hipMemsetAsync(queue, 0, sizeof(unsigned int), s));
     ProfScope prof(s, RECO_PROF_TOWER);
     if (t->img_split)
         return tower_launch_tile_split(t->G, t->has_l3, t->img_split, P, Qready ? Qready : Q, d.user_gmf, d.item_gmf, users,
@@ -574,9 +581,10 @@ extern "C" int reco_tower_score_matrix(reco_tower_t* t, const int64_t* users, in
         Q = reinterpret_cast<float*>(static_cast<char*>(ws) + kQueueBytes + proj_bytes(U));
     }
     const float* l1 = nullptr;
-    if ((rc = resolve_l1(t, t->d.user_mlp, t->d.n_users, t->d.item_mlp, t->d.n_items, queue, &l1, (hipStream_t)stream))) return rc;
+    bool clean = false;
+    if ((rc = resolve_l1(t, t->d.user_mlp, t->d.n_users, t->d.item_mlp, t->d.n_items, queue, &l1, &clean, (hipStream_t)stream))) return rc;
     const float* Qready = (t->mfma && !cands && N == t->d.n_items && t->Q) ? t->Q : nullptr;       // the whole catalogue: the handle's own projection
-    return score_matrix_impl(t, users, user_base, U, cands, N, Qready, l1, out, ld_out, P, Q, queue, oob, (hipStream_t)stream);
+    return score_matrix_impl(t, users, user_base, U, cands, N, Qready, l1, out, ld_out, P, Q, queue, clean, oob, (hipStream_t)stream);
 }
 
 // user-chunk size for the fused score + top-k path
@@ -699,7 +707,8 @@ static int score_topk_fused(reco_tower_t* t, const int64_t* users, int64_t user_
     const bool cached_q = !cands && N == d.n_items && t->Q;     // as the unfused form below
     int rc = RECO_OK;
     const float* l1 = nullptr;
-    if ((rc = resolve_l1(t, d.user_mlp, d.n_users, d.item_mlp, d.n_items, static_cast<unsigned int*>(ws), &l1, s))) return rc;
+    bool head_cleared = false;                                  // unused here: the fused form clears its own counters per chunk
+    if ((rc = resolve_l1(t, d.user_mlp, d.n_users, d.item_mlp, d.n_items, static_cast<unsigned int*>(ws), &l1, &head_cleared, s))) return rc;
     if (cached_q) Q = t->Q;
     else if ((rc = tower_project(t, nullptr, nullptr, 0, 0, d.item_mlp, cands, d.n_items, N, nullptr, Q, oob, l1, s))) return rc;
     for (int64_t c0 = 0; c0 < U; c0 += Uc) {
@@ -762,7 +771,8 @@ static int score_topk_impl(reco_tower_t* t, const int64_t* users, int64_t user_b
     // packed at creation instead (the serving path, inference_engine.py:149-166, and every full-catalogue batch step).
     const bool cached_q = t->mfma && !cands && N == d.n_items && t->Q;
     const float* l1 = nullptr;
-    if ((rc = resolve_l1(t, d.user_mlp, d.n_users, d.item_mlp, d.n_items, queue, &l1, s))) return rc;
+    bool clean = false;
+    if ((rc = resolve_l1(t, d.user_mlp, d.n_users, d.item_mlp, d.n_items, queue, &l1, &clean, s))) return rc;
     if (cached_q) Q = t->Q;
     else if (t->mfma) {
         rc = tower_project(t, nullptr, nullptr, 0, 0, d.item_mlp, cands, d.n_items, N, nullptr, Q, oob, l1, s);
@@ -770,7 +780,7 @@ static int score_topk_impl(reco_tower_t* t, const int64_t* users, int64_t user_b
     }
     for (int64_t c0 = 0; c0 < U; c0 += Uc) {
         const int64_t n = U - c0 < Uc ? U - c0 : Uc;
-        rc = score_matrix_impl(t, users ? users + c0 : nullptr, user_base + c0, n, cands, N, Q, l1, scores, ldN, P, Q, queue, oob, s);
+        rc = score_matrix_impl(t, users ? users + c0 : nullptr, user_base + c0, n, cands, N, Q, l1, scores, ldN, P, Q, queue, clean && c0 == 0, oob, s);
         if (rc) return rc;
         rc = launch_topk_rows_ex(scores, n, N, ldN, k, exclude ? exclude + c0 * ld_ex : nullptr, ld_ex, seen ? seen + c0 * ld_seen : nullptr,
                                  ld_seen, nullptr, n, nullptr, out_ids + c0 * k, out_scores + c0 * k, tws, tws_bytes, s);

@@ -875,7 +875,7 @@ __global__ __launch_bounds__(H1) void l1norms_kernel(const float* __restrict__ W
 // {s, 1/s} from the bound  max_f (|W1u_f|_1 mu + |b1_f|) + max_f |W1i_f|_1 mi  on p + q (tower_shared.h), mu / mi = the largest finite
 // |element| of the user / item rows.  ONE launch (it runs per call for the Hybrid head, whose rows are that call's latents):
 // workgroups [0, gu) scan the user rows, the rest the item rows, each folds its maximum into scratch[0] / scratch[1] (a float's
-// bit pattern) with one atomic per wave; the workgroup that draws the last ticket (scratch[2]) reads both maxima back and writes
+// bit pattern) with one atomic; the workgroup that draws the last ticket (scratch[2]) reads both maxima back and writes
 // the scale.  scratch[0..2] are zeroed by the launcher.  Only atomics carry data between workgroups.
 __global__ __launch_bounds__(256) void l1scale_kernel(const float* __restrict__ u_rows, int64_t u_elems, const float* __restrict__ i_rows,
                                                       int64_t i_elems, unsigned gu, unsigned gi, const float* __restrict__ norms,
@@ -883,13 +883,14 @@ __global__ __launch_bounds__(256) void l1scale_kernel(const float* __restrict__ 
 {
     __shared__ unsigned s_ticket;
     __shared__ float s_red[2][2];
+    __shared__ float s_max[4];
     const int tid = threadIdx.x;
     const bool user_side = blockIdx.x < gu;
     const unsigned b = user_side ? blockIdx.x : blockIdx.x - gu, g = user_side ? gu : gi;
+    float m = 0.f;
     if (b < g) {
         const float* x = user_side ? u_rows : i_rows;
         const int64_t n = user_side ? u_elems : i_elems;
-        float m = 0.f;
         const int64_t n4 = n / 4;
         for (int64_t i = (int64_t)b * 256 + tid; i < n4; i += (int64_t)g * 256) {
             const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
@@ -905,11 +906,15 @@ __global__ __launch_bounds__(256) void l1scale_kernel(const float* __restrict__ 
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        if ((tid & 63) == 0 && m > 0.f) atomicMax(scratch + (user_side ? 0 : 1), __float_as_uint(m));
     }
-    __threadfence();
-    __syncthreads();                                           // every wave's maximum is out before the ticket is drawn
-    if (tid == 0) s_ticket = atomicAdd(scratch + 2, 1u);
+    if ((tid & 63) == 0) s_max[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {                                            // one atomic per workgroup, then its ticket
+        m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+        if (m > 0.f) atomicMax(scratch + (user_side ? 0 : 1), __float_as_uint(m));
+        __threadfence();
+        s_ticket = atomicAdd(scratch + 2, 1u);
+    }
     __syncthreads();
     if (s_ticket != gridDim.x - 1) return;                     // workgroup-uniform
     __threadfence();
@@ -1118,11 +1123,13 @@ int tower_launch_l1norms(const float* W1, const float* b1, int dm, float* norms,
 }
 
 // out[0..1] = {s, 1/s} for layer 1 over the given user / item rows (tower_shared.h); norms: tower_launch_l1norms of the handle's
-// layer 1; scratch: 3 words, cleared here.  One memset node and one launch on `s`; nothing is read back.
+// layer 1; scratch: 3 words inside [clear, clear + clear_bytes), the region zeroed here first (a caller whose workspace head holds
+// other per-launch counters has them cleared by the same memset node).  One memset node and one launch on `s`; nothing is read back.
 int tower_launch_l1scale(const float* norms, const float* u_rows, int64_t u_elems, const float* i_rows, int64_t i_elems,
-                         unsigned int* scratch, float* out, hipStream_t s)
+                         unsigned int* scratch, float* out, void* clear, size_t clear_bytes, hipStream_t s)
 {
-    RECO_CHECK_HIP(hipMemsetAsync(scratch, 0, 3 * sizeof(unsigned int), s));
+    RECO_REQUIRE((char*)clear <= (char*)scratch && (char*)(scratch + 3) <= (char*)clear + clear_bytes, "internal: l1 scratch outside the cleared region");
+    RECO_CHECK_HIP(hipMemsetAsync(clear, 0, clear_bytes, s));
     auto side_blocks = [](int64_t elems) -> unsigned {
         if (elems <= 0) return 0u;
         const int64_t blocks = ceil_div64(elems, 256 * 16);
