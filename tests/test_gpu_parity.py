@@ -3,8 +3,15 @@ import numpy as np
 import pytest
 import torch
 
+import os
+
 from conftest import assert_close, golden_sd
 from oracle import reco_oracle as O
+
+# the seeded sweeps below run FUZZ_MULT times as many cases from FUZZ_SEED + their own seed (default: the committed cases);
+# RECO_FUZZ_MULT=25 RECO_FUZZ_SEED=<n> is the long hunt of tools/fuzz_run.sh
+FUZZ_MULT = max(1, int(os.environ.get("RECO_FUZZ_MULT", "1")))
+FUZZ_SEED = int(os.environ.get("RECO_FUZZ_SEED", "0"))
 
 pytestmark = pytest.mark.gpu
 
@@ -522,8 +529,8 @@ def test_two_narrow_layers_in_one_launch_equal_two_linear_calls_bit_for_bit():
 def test_linear_random_shape_sweep(tower_precision):
     """Seeded sweep over ragged shapes and alignments (K odd -> 4-byte loads, K even -> 8-byte, strided A / C views)."""
     from recommender_amd import ops
-    rng = np.random.default_rng(2026)
-    for case in range(36):
+    rng = np.random.default_rng(2026 + FUZZ_SEED)
+    for case in range(36 * FUZZ_MULT):
         M = int(rng.integers(1, 400)); N = int(rng.integers(1, 300))
         K = int(rng.choice([rng.integers(1, 64), rng.integers(64, 700), rng.integers(1024, 3000)]))
         x = rng.standard_normal((M, K + 5)).astype(np.float32); w = rng.standard_normal((N, K)).astype(np.float32)
@@ -544,8 +551,8 @@ def test_topk_random_sweep():
     """Seeded sweep: row lengths around the vector-load switch (1024), k around the one/two-slot switch (64), row views with
     a leading dimension larger than N, masks, heavy ties."""
     from recommender_amd import ops
-    rng = np.random.default_rng(77)
-    for case in range(40):
+    rng = np.random.default_rng(77 + FUZZ_SEED)
+    for case in range(40 * FUZZ_MULT):
         rows = int(rng.integers(1, 40))
         N = int(rng.choice([rng.integers(1, 130), rng.integers(1000, 1100), rng.integers(4000, 9000), 4096, 1024]))
         k = int(min(N, rng.choice([1, 5, 10, 63, 64, 65, 100, 128])))
@@ -613,8 +620,8 @@ def test_tower_random_request_sweep(g2, tag, tower_precision):
     m = _ncf_from_sd(golden_sd(g2, tag))
     ref = g2[tag + "__scores"]
     U, I = ref.shape
-    rng = np.random.default_rng(11)
-    for trial in range(24):
+    rng = np.random.default_rng(11 + FUZZ_SEED)
+    for trial in range(24 * FUZZ_MULT):
         nu = int(rng.integers(1, 70)); nc = int(rng.integers(1, 140))
         users = rng.integers(0, U, nu); cands = rng.integers(0, I, nc)            # repeats allowed on both sides
         ut = torch.from_numpy(users).cuda(); ct = torch.from_numpy(cands).cuda()
@@ -655,6 +662,55 @@ def test_topk_many_short_rows_lane_kernel():
         assert np.array_equal(ids.cpu().numpy(), oid), (rows, N, k, pad)
         got = vals.cpu().numpy()
         assert np.array_equal(np.isnan(got), np.isnan(oval)) and np.array_equal(np.nan_to_num(got), np.nan_to_num(oval)), (rows, N, k, pad)
+
+
+def test_topk_lane_kernels_random_sweep():
+    """Seeded sweep over the lane-per-row kernels' whole domain (>= 32,768 rows, N <= 512, k <= 16): random row lengths, k, padded
+    leading dimensions (which decide between the select-then-order kernel and the register-list kernel), ties, a NaN row."""
+    from recommender_amd import ops
+    rng = np.random.default_rng(909 + FUZZ_SEED)
+    for case in range(10 * FUZZ_MULT):
+        rows = int(rng.integers(32768, 36000))
+        N = int(rng.choice([rng.integers(1, 40), 4 * rng.integers(1, 41), rng.integers(40, 513), 100]))
+        k = int(min(N, rng.integers(1, 17)))
+        pad = int(rng.choice([0, 0, 4, 1, 2]))
+        full = rng.standard_normal((rows, N + pad)).astype(np.float32)
+        if case % 3 == 1:
+            full = np.round(full * 2) / 2
+        if case % 3 == 2:
+            full = np.round(full)                                # very heavy ties
+        full[rows - 1, : min(3, N)] = [np.nan, np.inf, -np.inf][: min(3, N)]
+        ids, vals = ops.topk_rows(torch.from_numpy(full).cuda()[:, :N], k)
+        oid, oval = O.topk_rows(full[:, :N], k)
+        assert np.array_equal(ids.cpu().numpy(), oid), (case, rows, N, k, pad)
+        got = vals.cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(oval)) and np.array_equal(np.nan_to_num(got), np.nan_to_num(oval)), (case, rows, N, k, pad)
+
+
+def test_csr_linear_random_sweep():
+    """Seeded sweep of the sparse first layer against the dense MFMA layer and fp64: random shapes on both column widths (4 / 8
+    columns per lane, generic form for N % 4 != 0), densities from empty to full, skewed rows (segment cap 96), both tables."""
+    from recommender_amd import ops
+    rng = np.random.default_rng(4242 + FUZZ_SEED)
+    for case in range(8 * FUZZ_MULT):
+        M = int(rng.integers(1, 300)); K = int(rng.integers(1, 2500))
+        N = int(rng.choice([4 * rng.integers(1, 65), 4 * rng.integers(65, 200), rng.integers(1, 600)]))
+        dens = float(rng.choice([0.0, 0.01, 0.05, 0.3, 1.0]))
+        X = ((rng.random((M, K)) < dens) * rng.integers(1, 6, (M, K))).astype(np.float32)
+        if case % 2 and dens > 0:
+            X[int(rng.integers(0, M))] = rng.integers(1, 6, K)          # one full row among sparse ones: the skewed cap
+        W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32); b = rng.standard_normal(N).astype(np.float32)
+        act = [None, "relu", "sigmoid"][case % 3]
+        Xd = torch.from_numpy(X).cuda(); Wd = torch.from_numpy(W).cuda(); bd = torch.from_numpy(b).cuda()
+        csr = ops.CsrMatrix.from_dense(Xd, k_ranges=[8, 1, 3][case % 3])
+        got = ops.csr_linear(csr, ops.transpose(Wd), bd if case % 4 else None, act).cpu().numpy()
+        bb = b if case % 4 else np.zeros_like(b)
+        pre64 = X.astype(np.float64) @ W.astype(np.float64).T + bb
+        ref64 = {"sigmoid": lambda v: 1 / (1 + np.exp(-v)), "relu": lambda v: np.maximum(v, 0), None: lambda v: v}[act](pre64)
+        slack = 2e-7 * (np.abs(X).astype(np.float64) @ np.abs(W).astype(np.float64).T + np.abs(bb))
+        err = np.abs(got - ref64)
+        tol = 1e-5 * np.maximum(np.abs(got), np.abs(ref64)) + 1e-6 + slack
+        assert (err <= tol).all(), (case, M, K, N, dens, float((err / tol).max()))
 
 
 @pytest.mark.parametrize("scale", [1e-6, 0.01, 1.0, 25.0, 3000.0])
