@@ -713,6 +713,58 @@ def test_csr_linear_random_sweep():
         assert (err <= tol).all(), (case, M, K, N, dens, float((err / tol).max()))
 
 
+def test_autorec_and_hybrid_random_size_sweep():
+    """Seeded sweep over matrix sizes the fixtures do not hold (users / items from a handful to ~700, densities from 1 % to 60 %,
+    ratings 1..5 and 0/1): AutoRec reconstruct_all + masked top-k and Hybrid score_all + masked top-k, dense and with the matrix
+    attached as CSR, against the oracle's fp32 restatement; the selects bit-exact on the kernels' own scores."""
+    from recommender_amd.autorec.utils.model import AutoRec
+    from recommender_amd.hybridautorecncf.model import HybridAutoRecNCF
+    rng = np.random.default_rng(606 + FUZZ_SEED)
+    for case in range(6 * FUZZ_MULT):
+        U = int(rng.integers(3, 700)); I = int(rng.integers(12, 700)); dens = float(rng.choice([0.01, 0.05, 0.2, 0.6]))
+        R = (rng.random((U, I)) < dens).astype(np.float32)
+        if case % 2 == 0:
+            R *= rng.integers(1, 6, (U, I)).astype(np.float32)
+        Rd = torch.from_numpy(R).cuda()
+        k = int(rng.integers(1, min(I, 20) + 1))
+        torch.manual_seed(1000 + case)
+        # ---- AutoRec (item-based: rows of X are item vectors over the users) ----
+        H = int(rng.choice([16, 64, 500, 37 * 4]))
+        a = AutoRec(U, I, H, True).eval()
+        sd = {n: v.detach().numpy().copy() for n, v in a.state_dict().items()}
+        a = a.cuda()
+        ref = O.autorec_forward(sd, np.ascontiguousarray(R.T), np.float32, clamp=(1.0, 5.0)).T
+        ref64 = O.autorec_forward(sd, np.ascontiguousarray(R.T), np.float64, clamp=(1.0, 5.0)).T
+        atol = 2.0 * float(np.abs(ref - ref64).max()) + 2e-6
+        for sparse in (False, True):
+            if sparse:
+                a.attach_ratings(Rd)
+            pred = a.reconstruct_all(Rd).cpu().numpy()
+            assert_close(pred, ref64, atol=atol, what="autorec %dx%d H=%d sparse=%s" % (U, I, H, sparse))
+            ids, vals = a.recommend_topk(Rd, k)
+            oid, oval = O.topk_rows(O.mask_seen(np.ascontiguousarray(pred), R > 0), k)
+            assert np.array_equal(ids.cpu().numpy(), oid) and np.array_equal(vals.cpu().numpy(), oval), ("autorec", case, U, I, H, k, sparse)
+        # ---- Hybrid ----
+        rating = bool(case % 3 == 0)
+        m = HybridAutoRecNCF(U, I, 64, [128, 64], rating_output=rating).eval()
+        hsd = {n: v.detach().numpy().copy() for n, v in m.state_dict().items()}
+        m = m.cuda()
+        want = O.hybrid_score_all(hsd, R, np.float32, rating=rating)
+        want64 = O.hybrid_score_all(hsd, R, np.float64, rating=rating)
+        # the gate's absolute part follows the reference arithmetic's own fp32 error on this matrix, as for AutoRec above (a dense
+        # 1..5 matrix drives the untrained encoders to latents whose head sums cancel: the oracle's fp32 and fp64 then differ by
+        # 7.7e-6 on a 208 x 158 case, 2.5 times the plain gate)
+        hatol = 2.0 * float(np.abs(want - want64).max()) + 2e-6
+        for sparse in (False, True):
+            if sparse:
+                m.attach_ratings(Rd)
+            S = m.score_all(Rd).cpu().numpy()
+            assert_close(S, want64, atol=hatol, what="hybrid %dx%d sparse=%s" % (U, I, sparse))
+            ids, vals = m.score_all(Rd, k=k, mask_seen=True)
+            oid, oval = O.topk_rows(O.mask_seen(S.copy(), R > 0), k)
+            assert np.array_equal(ids.cpu().numpy(), oid) and np.array_equal(vals.cpu().numpy(), oval), ("hybrid", case, U, I, k, sparse)
+
+
 @pytest.mark.parametrize("scale", [1e-6, 0.01, 1.0, 25.0, 3000.0])
 def test_tile_kernels_equal_the_pair_kernel_bit_for_bit_at_any_embedding_scale(scale):
     """Tile kernels and pair-list kernel share the MFMA body, the clamped layer 1 (tower_shared.h layer1_scale) and the summation
