@@ -845,17 +845,25 @@ __global__ __launch_bounds__(256) void gmf_tile_kernel(GmfTileArgs a)
     if (n >= a.N) return;
     const int64_t id = clamp_id(a.cands ? a.cands[n] : n, a.n_items, blockIdx.y == 0 ? a.oob : nullptr);
     const f32x4* gi = reinterpret_cast<const f32x4*>(a.EIg + id * a.G);
+    // Same summation as gmf_pairs_kernel, so that forward(u, i) and score_matrix()[u, i] of one model carry the same bits: eight
+    // chains (chunk c feeds chain c % 8, as the pair kernel's eight lanes do), folded pairwise like its xor-1 / 2 / 4 shuffles.
     for (int uu = 0; uu < 16 && u0 + uu < a.U; ++uu) {
-        float part = 0.f;
-        for (int c = 0; c < a.G / 4; ++c) {
-            const f32x4 g = gi[c];
-            const f32x4 gu = *reinterpret_cast<const f32x4*>(s_u + uu * a.G + 4 * c);
-            const f32x4 w = reinterpret_cast<const f32x4*>(a.wp)[c];
-            part = fmaf(gu.x * g.x, w.x, part);
-            part = fmaf(gu.y * g.y, w.y, part);
-            part = fmaf(gu.z * g.z, w.z, part);
-            part = fmaf(gu.w * g.w, w.w, part);
+        float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int c0 = 0; c0 < a.G / 4; c0 += 8) {
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                const int c = c0 + l;
+                if (c >= a.G / 4) break;
+                const f32x4 g = gi[c];
+                const f32x4 gu = *reinterpret_cast<const f32x4*>(s_u + uu * a.G + 4 * c);
+                const f32x4 w = reinterpret_cast<const f32x4*>(a.wp)[c];
+                p[l] = fmaf(gu.x * g.x, w.x, p[l]);
+                p[l] = fmaf(gu.y * g.y, w.y, p[l]);
+                p[l] = fmaf(gu.z * g.z, w.z, p[l]);
+                p[l] = fmaf(gu.w * g.w, w.w, p[l]);
+            }
         }
+        const float part = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
         a.out[(u0 + uu) * a.ld_out + n] = epilogue(part + a.bp, a.act, a.lo, a.hi);
     }
 }

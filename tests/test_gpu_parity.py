@@ -713,6 +713,45 @@ def test_csr_linear_random_sweep():
         assert (err <= tol).all(), (case, M, K, N, dens, float((err / tol).max()))
 
 
+def test_neumf_random_table_size_sweep():
+    """Seeded sweep over table sizes (1..3,000 users x 10..40,000 items) and all three model kinds: the full catalogue for a user
+    range through the two-kernel form, the fused score + top-k kernel and a user LIST (per-call projections) must agree bit for
+    bit; sampled rows against the oracle (fp32 gate) and the select against the oracle's rule on the kernel's own scores; a pair
+    list of the same model equals the matrix entries bit for bit."""
+    from recommender_amd.helpers import NCF
+    rng = np.random.default_rng(808 + FUZZ_SEED)
+    for case in range(6 * FUZZ_MULT):
+        n_users = int(rng.integers(1, 3000)); n_items = int(rng.choice([rng.integers(10, 200), rng.integers(200, 5000), rng.integers(5000, 40000)]))
+        name = ["NeuMF-end", "MLP", "GMF"][case % 3]
+        torch.manual_seed(2000 + case)
+        m = NCF(n_users, n_items, 32, 3, 0.0, name).eval()
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if "embed" in n:
+                    p.mul_(float(rng.choice([1.0, 25.0])))
+        sd = {k_: v.detach().numpy().copy() for k_, v in m.state_dict().items()}
+        m = m.cuda()
+        tower = m._tower(torch.device("cuda", 0))
+        k = int(rng.integers(1, min(n_items, 128) + 1))
+        lo = int(rng.integers(0, n_users)); cnt = int(rng.integers(1, n_users - lo + 1))
+        ids, vals = tower.score_topk((lo, cnt), k)
+        if name != "GMF":                                              # the fused form runs on the MFMA tower only
+            fi, fv = tower.score_topk((lo, cnt), k, fused=True)
+            assert torch.equal(fi, ids) and torch.equal(fv.view(torch.int32), vals.view(torch.int32)), ("fused", case, n_users, n_items, k)
+        ul = torch.arange(lo, lo + cnt, device="cuda")
+        li, lv = tower.score_topk(ul, k)
+        assert torch.equal(li, ids) and torch.equal(lv.view(torch.int32), vals.view(torch.int32)), ("user list", case, n_users, n_items, k)
+        pick = np.sort(rng.choice(cnt, min(cnt, 6), replace=False)) + lo
+        S = tower.score_matrix(torch.from_numpy(pick).cuda()).cpu().numpy()
+        assert_close(S, O.ncf_score_all(sd, pick), what="%s %dx%d rows vs oracle" % (name, n_users, n_items))
+        oid, oval = O.topk_rows(S, k)
+        assert np.array_equal(ids.cpu().numpy()[pick - lo], oid) and np.array_equal(vals.cpu().numpy()[pick - lo], oval), (case, name, n_users, n_items, k)
+        B = int(rng.integers(1, 5000))
+        pu = rng.choice(pick, B); pi = rng.integers(0, n_items, B)
+        pairs = m(torch.from_numpy(pu).cuda(), torch.from_numpy(pi).cuda()).cpu().numpy()
+        assert np.array_equal(pairs, S[np.searchsorted(pick, pu), pi]), ("pairs", case, name, B)
+
+
 def test_autorec_and_hybrid_random_size_sweep():
     """Seeded sweep over matrix sizes the fixtures do not hold (users / items from a handful to ~700, densities from 1 % to 60 %,
     ratings 1..5 and 0/1): AutoRec reconstruct_all + masked top-k and Hybrid score_all + masked top-k, dense and with the matrix
