@@ -752,6 +752,35 @@ def test_neumf_random_table_size_sweep():
         assert np.array_equal(pairs, S[np.searchsorted(pick, pu), pi]), ("pairs", case, name, B)
 
 
+def test_topk_workspace_limited_chunking_sweep():
+    """A workspace anywhere between what ONE user needs and what the whole request needs makes the call walk the users in chunks
+    (two-kernel and fused form, masks, candidate lists, the allocation-free entry point's fixed scratch): the answer never depends
+    on the chunking, bit for bit."""
+    from recommender_amd.helpers import NCF
+    rng = np.random.default_rng(1313 + FUZZ_SEED)
+    for case in range(6 * FUZZ_MULT):
+        n_users = int(rng.integers(40, 2500)); n_items = int(rng.choice([rng.integers(20, 300), rng.integers(300, 9000)]))
+        name = ["NeuMF-end", "MLP"][case % 2]
+        torch.manual_seed(3000 + case)
+        m = NCF(n_users, n_items, 32, 3, 0.0, name).eval().cuda()
+        tower = m._tower(torch.device("cuda", 0))
+        L = tower._L
+        k = int(rng.integers(1, min(n_items, 100) + 1))
+        users = torch.from_numpy(rng.integers(0, n_users, int(rng.integers(1, 1500)))).cuda() if case % 3 else None
+        U = users.numel() if users is not None else n_users
+        cands = torch.from_numpy(rng.integers(0, n_items, int(rng.integers(k, 2 * n_items)))).cuda() if case % 4 == 1 else None
+        N = cands.numel() if cands is not None else n_items
+        mask = torch.from_numpy(rng.random((U, N)) < 0.2).cuda() if case % 2 else None
+        want_i, want_v = tower.score_topk(users, k, cands, exclude=mask)
+        for fused in ((False, True) if mask is None else (False,)):
+            one = L.reco_tower_topk_fused_workspace_bytes(tower._h, 1, N, k) if fused else L.reco_tower_topk_workspace_bytes(1, N, k)
+            full = L.reco_tower_topk_fused_workspace_bytes(tower._h, U, N, k) if fused else L.reco_tower_topk_workspace_bytes(U, N, k)
+            for frac in (0.0, float(rng.random()) * 0.3, float(rng.random())):
+                ws = torch.empty(int(one + frac * max(full - one, 0)) + 256, dtype=torch.uint8, device="cuda")
+                ids, vals = tower.score_topk(users, k, cands, exclude=mask, ws=ws, fused=fused)
+                assert torch.equal(ids, want_i) and torch.equal(vals.view(torch.int32), want_v.view(torch.int32)), (case, name, U, N, k, fused, frac)
+
+
 def test_autorec_and_hybrid_random_size_sweep():
     """Seeded sweep over matrix sizes the fixtures do not hold (users / items from a handful to ~700, densities from 1 % to 60 %,
     ratings 1..5 and 0/1): AutoRec reconstruct_all + masked top-k and Hybrid score_all + masked top-k, dense and with the matrix
