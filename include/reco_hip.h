@@ -10,8 +10,10 @@
  * Conventions
  *   - every pointer is a DEVICE pointer unless the comment says "host";
  *   - floats are fp32, contiguous, row-major; Linear weights are [out, in] as nn.Linear stores them;
- *   - embedding tables, row blocks and gather outputs are 16-byte aligned and their widths multiples of 4 (rows move as
- *     float4; anything torch allocates qualifies); a violation is RECO_EINVAL, never a misaligned access;
+ *   - embedding tables and row blocks handed to a TOWER are 16-byte aligned and their widths multiples of 4 (rows move as
+ *     float4; anything torch allocates qualifies); a violation is RECO_EINVAL, never a misaligned access.  The stand-alone
+ *     gathers (K-a) take any width and alignment, as nn.Embedding does: widths that are not multiples of 4 or misaligned
+ *     pointers run a one-float-per-thread form of the same kernels;
  *   - ids (users, items, candidate lists) are int64 as the reference's torch LongTensors; returned
  *     top-k positions are int32;
  *   - `stream` is a hipStream_t passed as void*; work is only enqueued, never synchronised,
@@ -68,16 +70,17 @@ const char* reco_last_error(void);
  * replaces nn.Embedding.__call__            src/helpers/ncf_model.py:207-208,220-221
  * ---------------------------------------------------------------------------------------- */
 
-/* out[b, :] = table[idx[b], :]   dim % 4 == 0.  Out-of-range ids are clamped and counted in *oob
- * (device int32, nullable). */
+/* out[b, :] = table[idx[b], :]   any dim > 0 (dim % 4 == 0 and 16-byte aligned pointers: the float4 form).  Out-of-range
+ * ids are clamped and counted in *oob (device int32, nullable). */
 int reco_gather_rows(const float* table, int64_t rows, int dim, const int64_t* idx, int64_t B,
                      float* out, int32_t* oob, void* stream);
 
 /* Fused 4-table NeuMF gather: the tensors the reference materialises before its MLP,
  *   gmf_prod[b, :]  = Eu_g[user[b]] * Ei_g[item[b]]                  ncf_model.py:207-211
  *   mlp_in[b, :]    = [Eu_m[user[b]] | Ei_m[item[b]]]  (user half first) ncf_model.py:220-224
- * dg % 4 == 0, dm % 4 == 0.  Either output may be NULL to skip that half.  ld_gmf / ld_mlp are the
- * outputs' row strides in floats (multiples of 4; 0 = dense: dg and 2*dm), so a product can be
+ * Any dg / dm > 0 (the float4 form needs dg, dm and the strides to be multiples of 4 and 16-byte aligned pointers; anything
+ * else runs one float per thread).  Either output may be NULL to skip that half.  ld_gmf / ld_mlp are the
+ * outputs' row strides in floats (0 = dense: dg and 2*dm), so a product can be
  * written straight into a column block of a wider buffer (the predict layer's concat, ncf_model.py:240). */
 int reco_neumf_gather(const float* Eu_g, const float* Ei_g, const float* Eu_m, const float* Ei_m,
                       int64_t n_users, int64_t n_items, int dg, int dm,

@@ -134,6 +134,55 @@ __global__ __launch_bounds__(256) void neumf_gather_kernel(FusedArgs a, int sh_m
     }
 }
 
+// Any row width / alignment (an embedding of factor_num = 10, a view at an odd column): one float per thread.  Off the hot path --
+// every shipped model has widths that are multiples of 4 -- but nn.Embedding takes any width and so do these entry points.
+__global__ __launch_bounds__(256) void gather_rows_any_kernel(const float* __restrict__ table, int64_t rows, int dim,
+                                                              const int64_t* __restrict__ idx, int64_t B, float* __restrict__ out, int32_t* oob)
+{
+    const int64_t total = B * dim;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t b = t / dim;
+        const int c = (int)(t - b * dim);
+        out[t] = table[clamp_row(idx[b], rows, oob, c == 0) * dim + c];
+    }
+}
+
+struct AnyArgs {
+    const float* Eu_g; const float* Ei_g; const float* Eu_m; const float* Ei_m;
+    int64_t n_users, n_items;
+    int dg, dm;
+    const int64_t* user; const int64_t* item;
+    int64_t B;
+    float* gmf_prod; float* mlp_in;
+    int64_t ldg, ldm;            // output row strides in floats
+    int32_t* oob;
+};
+
+__global__ __launch_bounds__(256) void neumf_gather_any_kernel(AnyArgs a)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    if (a.mlp_in) {
+        const int per_pair = 2 * a.dm;
+        const int64_t total = a.B * per_pair;
+        for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+            const int64_t b = t / per_pair;
+            const int c = (int)(t - b * per_pair);
+            a.mlp_in[b * a.ldm + c] = c < a.dm ? a.Eu_m[clamp_row(a.user[b], a.n_users, a.oob, c == 0) * a.dm + c]
+                                               : a.Ei_m[clamp_row(a.item[b], a.n_items, a.oob, c == a.dm) * a.dm + (c - a.dm)];
+        }
+    }
+    if (a.gmf_prod) {
+        const int64_t total = a.B * a.dg;
+        for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+            const int64_t b = t / a.dg;
+            const int c = (int)(t - b * a.dg);
+            const bool count = c == 0 && !a.mlp_in;
+            a.gmf_prod[b * a.ldg + c] = a.Eu_g[clamp_row(a.user[b], a.n_users, a.oob, count) * a.dg + c] *
+                                        a.Ei_g[clamp_row(a.item[b], a.n_items, a.oob, count) * a.dg + c];
+        }
+    }
+}
+
 static int log2_exact(int v)
 {
     int s = 0;
@@ -154,11 +203,15 @@ extern "C" int reco_gather_rows(const float* table, int64_t rows, int dim, const
 {
     if (B <= 0) return RECO_OK;
     RECO_REQUIRE(table && idx && out, "gather_rows: null pointer");
-    RECO_REQUIRE(dim > 0 && dim % 4 == 0, "gather_rows: dim must be a positive multiple of 4, got %d", dim);
+    RECO_REQUIRE(dim > 0, "gather_rows: dim must be positive, got %d", dim);
     RECO_REQUIRE(rows > 0, "gather_rows: empty table");
-    RECO_REQUIRE((uintptr_t)table % 16 == 0 && (uintptr_t)out % 16 == 0, "gather_rows: table and out must be 16-byte aligned");
-    const int sh = log2_exact(dim / 4);
     ProfScope prof((hipStream_t)stream, RECO_PROF_GATHER);
+    if (dim % 4 != 0 || (uintptr_t)table % 16 != 0 || (uintptr_t)out % 16 != 0) {      // any width / alignment: the scalar form
+        hipLaunchKernelGGL(gather_rows_any_kernel, dim3(stream_grid(B * dim)), dim3(256), 0, (hipStream_t)stream, table, rows, dim, idx, B, out, oob);
+        RECO_CHECK_LAUNCH();
+        return RECO_OK;
+    }
+    const int sh = log2_exact(dim / 4);
     if (sh >= 0)
         hipLaunchKernelGGL(gather_rows_kernel<true>, dim3(stream_grid(B * (dim / 4))), dim3(256), 0, (hipStream_t)stream,
                            table, rows, dim / 4, sh, idx, B, out, oob);
@@ -177,16 +230,23 @@ extern "C" int reco_neumf_gather(const float* Eu_g, const float* Ei_g, const flo
 {
     if (B <= 0) return RECO_OK;
     RECO_REQUIRE(user && item, "neumf_gather: null id pointer");
-    RECO_REQUIRE(!gmf_prod || (Eu_g && Ei_g && dg > 0 && dg % 4 == 0), "neumf_gather: bad GMF tables / dg=%d", dg);
-    RECO_REQUIRE(!mlp_in || (Eu_m && Ei_m && dm > 0 && dm % 4 == 0), "neumf_gather: bad MLP tables / dm=%d", dm);
+    RECO_REQUIRE(!gmf_prod || (Eu_g && Ei_g && dg > 0), "neumf_gather: bad GMF tables / dg=%d", dg);
+    RECO_REQUIRE(!mlp_in || (Eu_m && Ei_m && dm > 0), "neumf_gather: bad MLP tables / dm=%d", dm);
     RECO_REQUIRE(n_users > 0 && n_items > 0, "neumf_gather: empty tables");
     if (ld_gmf == 0) ld_gmf = dg;
     if (ld_mlp == 0) ld_mlp = 2 * dm;
-    RECO_REQUIRE(ld_gmf % 4 == 0 && ld_mlp % 4 == 0 && (!gmf_prod || ld_gmf >= dg) && (!mlp_in || ld_mlp >= 2 * dm),
+    RECO_REQUIRE((!gmf_prod || ld_gmf >= dg) && (!mlp_in || ld_mlp >= 2 * dm),
                  "neumf_gather: bad output strides %lld / %lld", (long long)ld_gmf, (long long)ld_mlp);
-    RECO_REQUIRE((uintptr_t)gmf_prod % 16 == 0 && (uintptr_t)mlp_in % 16 == 0, "neumf_gather: outputs must be 16-byte aligned");
-    RECO_REQUIRE((uintptr_t)Eu_g % 16 == 0 && (uintptr_t)Ei_g % 16 == 0 && (uintptr_t)Eu_m % 16 == 0 && (uintptr_t)Ei_m % 16 == 0,
-                 "neumf_gather: tables must be 16-byte aligned");
+    const bool vec4 = (!gmf_prod || (dg % 4 == 0 && ld_gmf % 4 == 0)) && (!mlp_in || (dm % 4 == 0 && ld_mlp % 4 == 0)) &&
+                      (uintptr_t)gmf_prod % 16 == 0 && (uintptr_t)mlp_in % 16 == 0 && (uintptr_t)Eu_g % 16 == 0 &&
+                      (uintptr_t)Ei_g % 16 == 0 && (uintptr_t)Eu_m % 16 == 0 && (uintptr_t)Ei_m % 16 == 0;
+    if (!vec4) {                                         // any width / alignment: the scalar form
+        AnyArgs any{Eu_g, Ei_g, Eu_m, Ei_m, n_users, n_items, dg, dm, user, item, B, gmf_prod, mlp_in, ld_gmf, ld_mlp, oob};
+        ProfScope prof((hipStream_t)stream, RECO_PROF_GATHER);
+        hipLaunchKernelGGL(neumf_gather_any_kernel, dim3(stream_grid(B * (mlp_in ? 2 * dm : dg))), dim3(256), 0, (hipStream_t)stream, any);
+        RECO_CHECK_LAUNCH();
+        return RECO_OK;
+    }
     FusedArgs a{Eu_g, Ei_g, Eu_m, Ei_m, n_users, n_items, dg / 4, dm / 4, user, item, B, gmf_prod, mlp_in, ld_gmf / 4, ld_mlp / 4, oob};
     const int64_t work = B * (mlp_in ? 2 * (dm / 4) : dg / 4);
     const int sh_m = mlp_in ? log2_exact(2 * (dm / 4)) : 0, sh_g = gmf_prod ? log2_exact(dg / 4) : 0;

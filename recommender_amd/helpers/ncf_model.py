@@ -126,7 +126,10 @@ class NCF(nn.Module):
         rating = self._rating_epilogue()
         layers = own.get("layers", [])
         widths = [w.shape[0] for w, _ in layers]
-        fused = (not layers) or (widths == [128, 64, 32] and ("embed_user_GMF" not in own or own["embed_user_GMF"].shape[1] == 32))
+        # GMF-only: the float4 GMF kernels (any width that is a multiple of 4); NeuMF / MLP factor 32 x 3 layers: the MFMA tower;
+        # everything else (other factors and depths, widths that are not multiples of 4): the unfused all-HIP path
+        fused = (not layers and own["embed_user_GMF"].shape[1] % 4 == 0) or \
+                (widths == [128, 64, 32] and ("embed_user_GMF" not in own or own["embed_user_GMF"].shape[1] == 32))
         tower = (ops.Tower if fused else ops.GenericTower)(
             user_gmf=dev(own["embed_user_GMF"]) if "embed_user_GMF" in own else None,
             item_gmf=dev(own["embed_item_GMF"]) if "embed_item_GMF" in own else None,

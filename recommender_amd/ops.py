@@ -747,9 +747,6 @@ class GenericTower:
         self.n_users, self.n_items = tab_u.shape[0], tab_i.shape[0]
         self.dg = 0 if self.ug is None else self.ug.shape[1]
         self.dout = self.layers[-1][0].shape[0] if self.layers else 0
-        for t in (self.ug, self.um):
-            if t is not None and t.shape[1] % 4:
-                raise ValueError("reco_hip: embedding widths must be multiples of 4, got %d" % t.shape[1])
         if self.dg + self.dout != self.wp.shape[1]:
             raise ValueError("predict layer width %d does not match gmf %d + mlp %d" % (self.wp.shape[1], self.dg, self.dout))
 

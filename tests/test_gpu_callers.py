@@ -197,7 +197,7 @@ def test_c_abi_rejects_bad_arguments_with_error_codes_not_faults():
     refused(L.reco_topk_rows(p(x), 8, 16, 16, 17, None, 0, p(ids), p(vals), None, 0, st), _lib.EINVAL, "exceeds")
     refused(L.reco_topk_rows(p(x), 8, 16, 8, 3, None, 0, p(ids), p(vals), None, 0, st), _lib.EINVAL, "ld smaller")
     idx = torch.zeros(4, dtype=torch.int64, device=dev)
-    refused(L.reco_gather_rows(p(x), 8, 6, p(idx), 4, p(y), None, st), _lib.EINVAL, "multiple of 4")
+    refused(L.reco_gather_rows(p(x), 8, 0, p(idx), 4, p(y), None, st), _lib.EINVAL, "must be positive")
 
     d = _lib.TowerDesc()                                     # a tower with no branch at all
     h = ctypes.c_void_p()

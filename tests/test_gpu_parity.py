@@ -781,6 +781,76 @@ def test_topk_workspace_limited_chunking_sweep():
                 assert torch.equal(ids, want_i) and torch.equal(vals.view(torch.int32), want_v.view(torch.int32)), (case, name, U, N, k, fused, frac)
 
 
+def test_gather_mlp2_and_seen_select_random_sweep():
+    """Seeded sweeps of the three small stand-alone ops: row gathers (any row width, repeated ids), the two-layer launch at every
+    width combination it accepts, and the select that reads the seen mask off the rating matrix with users picked by id."""
+    from recommender_amd import ops
+    rng = np.random.default_rng(5150 + FUZZ_SEED)
+    c = lambda a: torch.from_numpy(a).cuda()
+    for case in range(8 * FUZZ_MULT):
+        rows = int(rng.integers(1, 6000)); D = int(rng.choice([1, 3, 4, 8, 30, 32, 64, 100, 128, 256, 516]))
+        table = rng.standard_normal((rows, D)).astype(np.float32)
+        idx = rng.integers(0, rows, int(rng.integers(0, 9000)))
+        assert np.array_equal(ops.gather_rows(c(table), c(idx)).cpu().numpy(), table[idx]), ("gather", case, rows, D)
+        dg = int(rng.choice([8, 16, 32, 64, 10, 3])); dm = int(rng.choice([16, 32, 64, 128, 40, 5]))
+        nu = int(rng.integers(1, 3000)); ni = int(rng.integers(1, 3000)); B = int(rng.integers(1, 7000))
+        eu_g = rng.standard_normal((nu, dg)).astype(np.float32); ei_g = rng.standard_normal((ni, dg)).astype(np.float32)
+        eu_m = rng.standard_normal((nu, dm)).astype(np.float32); ei_m = rng.standard_normal((ni, dm)).astype(np.float32)
+        u = rng.integers(0, nu, B); i = rng.integers(0, ni, B)
+        gp, mi = ops.neumf_gather(c(eu_g), c(ei_g), c(eu_m), c(ei_m), c(u), c(i))
+        assert np.array_equal(gp.cpu().numpy(), eu_g[u] * ei_g[i]) and np.array_equal(mi.cpu().numpy(), np.concatenate([eu_m[u], ei_m[i]], 1)), ("neumf_gather", case)
+    widths = [8, 16, 32, 64, 128, 256, 512, 1024]
+    done = 0
+    while done < 6 * FUZZ_MULT:
+        K1, N2, N3 = (int(rng.choice(widths)) for _ in range(3))
+        if not ops.mlp2_supported(K1, N2, N3):
+            continue
+        done += 1
+        M = int(rng.integers(1, 5000))
+        x = c(rng.standard_normal((M, K1)).astype(np.float32))
+        w2 = c((rng.standard_normal((N2, K1)) / np.sqrt(K1)).astype(np.float32)); w3 = c((rng.standard_normal((N3, N2)) / np.sqrt(N2)).astype(np.float32))
+        b2 = c(rng.standard_normal(N2).astype(np.float32)) if done % 2 else None
+        b3 = c(rng.standard_normal(N3).astype(np.float32)) if done % 3 else None
+        act3 = [None, "relu", "sigmoid"][done % 3]
+        got = ops.mlp2(x, w2, b2, w3, b3, "relu", act3)
+        want = ops.linear(ops.linear(x, w2, b2, "relu", precision="f32"), w3, b3, act3, precision="f32")
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32)), ("mlp2", M, K1, N2, N3, act3)
+    for case in range(6 * FUZZ_MULT):
+        U = int(rng.integers(1, 300)); N = int(rng.choice([rng.integers(1, 200), rng.integers(900, 1100), rng.integers(3000, 9000)]))
+        k = int(min(N, rng.choice([1, 3, 10, 64, 100, 128]))); pad = int(rng.choice([0, 1, 4, 6]))
+        sc = np.clip(rng.standard_normal((U, N)) * 2 + 3, 1.0, 5.0).astype(np.float32)
+        R = ((rng.random((U, N)) < rng.choice([0.0, 0.05, 0.5, 0.98])) * rng.integers(1, 6, (U, N))).astype(np.float32)
+        buf = torch.zeros((U, N + pad), dtype=torch.float32, device="cuda")
+        buf[:, :N] = c(sc)
+        users = rng.integers(0, U, int(rng.integers(1, 400)))
+        ids, vals = ops.topk_rows_seen(buf[:, :N], k, c(R), c(users))
+        oid, oval = O.topk_rows(O.mask_seen(sc, R > 0)[users], k)
+        assert np.array_equal(ids.cpu().numpy(), oid) and np.array_equal(vals.cpu().numpy(), oval), ("seen select", case, U, N, k, pad)
+
+
+@pytest.mark.parametrize("factor,layers,name", [(10, 3, "NeuMF-end"), (6, 2, "MLP"), (7, 1, "GMF"), (10, 3, "NeuMF-pre")])
+def test_factor_numbers_that_are_not_multiples_of_4(factor, layers, name):
+    """nn.Embedding takes any width: an NCF with factor_num = 10 (GMF rows of 10 floats, MLP rows of 40) or 6 / 7 runs on the unfused
+    HIP path through the one-float-per-thread gathers; pair lists, matrix and top-k against the oracle."""
+    from recommender_amd.helpers import NCF
+    torch.manual_seed(factor)
+    gmf = NCF(57, 83, factor, layers, 0.0, "GMF") if name == "NeuMF-pre" else None
+    mlp = NCF(57, 83, factor, layers, 0.0, "MLP") if name == "NeuMF-pre" else None
+    m = NCF(57, 83, factor, layers, 0.0, name, gmf, mlp).eval()
+    sd = {k_: v.detach().numpy().copy() for k_, v in m.state_dict().items()}
+    m = m.cuda()
+    rng = np.random.default_rng(factor)
+    u = rng.integers(0, 57, 700); i = rng.integers(0, 83, 700)
+    got = m(torch.from_numpy(u).cuda(), torch.from_numpy(i).cuda()).cpu().numpy()
+    assert_close(got, O.ncf_forward(sd, u, i), what="factor %d %s pairs" % (factor, name))
+    assert_close(got, O.ncf_forward(sd, u, i, np.float64), what="factor %d %s pairs vs fp64" % (factor, name))
+    S = m.score_matrix().cpu().numpy()
+    assert_close(S, O.ncf_score_all(sd, np.arange(57)), what="factor %d %s matrix" % (factor, name))
+    ids, vals = m.score_topk(None, 9)
+    oid, oval = O.topk_rows(S, 9)
+    assert np.array_equal(ids.cpu().numpy(), oid) and np.array_equal(vals.cpu().numpy(), oval)
+
+
 def test_autorec_and_hybrid_random_size_sweep():
     """Seeded sweep over matrix sizes the fixtures do not hold (users / items from a handful to ~700, densities from 1 % to 60 %,
     ratings 1..5 and 0/1): AutoRec reconstruct_all + masked top-k and Hybrid score_all + masked top-k, dense and with the matrix
