@@ -152,6 +152,22 @@ class NCF(nn.Module):
                 if m.bias is not None:
                     nn.init.zeros_(m.bias)
 
+    def _fused_shape(self):
+        """The MFMA head covers the shipped shape: latent 64, MLP 128 -> 128 -> 64 (hybridautorecncf notebooks); any other latent
+        width / layer list runs on the unfused all-HIP path (ops.GenericTower over this call's latents)."""
+        linears = [m for m in self.mlp if isinstance(m, nn.Linear)]
+        return [l.out_features for l in linears] == [128, 64] and self.output.in_features == 64 + 64
+
+    def _generic(self, zu, zi):
+        linears = [m for m in self.mlp if isinstance(m, nn.Linear)]
+        if not linears:
+            raise ValueError("recommender_amd hybrid NCF: an empty mlp_layers list is not supported")
+        dev = zu.device
+        return ops.GenericTower(user_gmf=zu, item_gmf=zi, user_mlp=zu, item_mlp=zi,
+                                layers=[(_f32_on(l.weight, dev), _f32_on(l.bias, dev)) for l in linears],
+                                w_predict=_f32_on(self.output.weight, dev), b_predict=_f32_on(self.output.bias, dev),
+                                act="rating" if self.rating_output else None, lo=float(self.rating_min), hi=float(self.rating_max))
+
     def _tower(self, device):
         linears = [m for m in self.mlp if isinstance(m, nn.Linear)]
         ps = [p for lin in linears for p in (lin.weight, lin.bias)] + [self.output.weight, self.output.bias]
@@ -175,7 +191,11 @@ class NCF(nn.Module):
         zu = _f32_on(user_z, device); zi = _f32_on(item_z, device)
         if zu.shape != zi.shape:
             raise ValueError("user_z and item_z must have the same shape")
-        out = self._tower(device).score_rows(zu, zi, zu, zi)
+        if self._fused_shape():
+            out = self._tower(device).score_rows(zu, zi, zu, zi)
+        else:
+            rows = torch.arange(zu.shape[0], device=device)
+            out = self._generic(zu, zi).score_pairs(rows, rows, check_ids=False)
         return out if out.device == src else out.to(src)
 
     def score_matrix(self, zu, zi, k=None, exclude=None, seen=None):
@@ -185,6 +205,15 @@ class NCF(nn.Module):
         ops.require_gpu()
         device = zu.device if zu.is_cuda else torch.device("cuda", torch.cuda.current_device())
         zu = _f32_on(zu, device); zi = _f32_on(zi, device)
+        if not self._fused_shape():
+            tower = self._generic(zu, zi)
+            if k is None:
+                return tower.score_matrix(check_ids=False)
+            if seen is None:
+                return tower.score_topk(None, k, None, exclude, check_ids=False)
+            if exclude is not None:
+                raise ValueError("give the seen items as a mask or as the rating matrix, not both")
+            return ops.topk_rows_seen(tower.score_matrix(check_ids=False), k, seen)
         tower = self._tower(device)
         if k is None:
             return tower.score_matrix_rows(zu, zi, zu, zi)

@@ -851,6 +851,36 @@ def test_factor_numbers_that_are_not_multiples_of_4(factor, layers, name):
     assert np.array_equal(ids.cpu().numpy(), oid) and np.array_equal(vals.cpu().numpy(), oval)
 
 
+@pytest.mark.parametrize("latent,layers,hidden", [(32, (64, 32), (128, 64)), (16, (64,), (40,)), (64, (128, 64, 32), (256, 128)), (10, (20, 8), (12, 6))])
+def test_hybrid_shapes_other_than_the_shipped_one(latent, layers, hidden):
+    """HybridAutoRecNCF takes any latent width, MLP layer list and encoder widths (evaluate_hybridautorecncf_rating.py:58-208); the
+    MFMA head covers latent 64 / [128, 64], everything else runs unfused, all-HIP: forward, score_all and the masked top-k
+    against the oracle."""
+    from recommender_amd.hybridautorecncf.model import HybridAutoRecNCF
+    torch.manual_seed(latent)
+    U, I = 71, 53
+    m = HybridAutoRecNCF(U, I, latent, list(layers), hidden_dims=hidden, rating_output=bool(latent % 3)).eval()
+    sd = {k_: v.detach().numpy().copy() for k_, v in m.state_dict().items()}
+    m = m.cuda()
+    rng = np.random.default_rng(latent)
+    R = ((rng.random((U, I)) < 0.2) * rng.integers(1, 6, (U, I))).astype(np.float32)
+    Rd = torch.from_numpy(R).cuda()
+    want = O.hybrid_score_all(sd, R, np.float32, rating=bool(latent % 3))
+    want64 = O.hybrid_score_all(sd, R, np.float64, rating=bool(latent % 3))
+    atol = 2.0 * float(np.abs(want - want64).max()) + 2e-6
+    S = m.score_all(Rd).cpu().numpy()
+    assert_close(S, want64, atol=atol, what="hybrid latent %d layers %s" % (latent, layers))
+    uu, ii = np.meshgrid(np.arange(U), np.arange(I), indexing="ij")
+    uid = torch.from_numpy(uu.reshape(-1)).cuda(); iid = torch.from_numpy(ii.reshape(-1)).cuda()
+    pred, urec, irec = m(Rd[uid], Rd.t().contiguous()[iid], uid, iid)
+    assert_close(pred.cpu().numpy().reshape(U, I), want64, atol=atol, what="forward")
+    ids, vals = m.score_all(Rd, k=7, mask_seen=True)
+    oid, oval = O.topk_rows(O.mask_seen(S.copy(), R > 0), 7)
+    assert np.array_equal(ids.cpu().numpy(), oid) and np.array_equal(vals.cpu().numpy(), oval)
+    ids, vals = m.score_all(Rd, k=7, exclude=torch.from_numpy(R > 0).cuda())
+    assert np.array_equal(ids.cpu().numpy(), oid) and np.array_equal(vals.cpu().numpy(), oval)
+
+
 def test_autorec_and_hybrid_random_size_sweep():
     """Seeded sweep over matrix sizes the fixtures do not hold (users / items from a handful to ~700, densities from 1 % to 60 %,
     ratings 1..5 and 0/1): AutoRec reconstruct_all + masked top-k and Hybrid score_all + masked top-k, dense and with the matrix
