@@ -100,6 +100,29 @@ def test_noalloc_topk_in_the_fused_form_when_the_score_rows_need_several_user_ch
     assert np.array_equal(ids_d, ids_b[100:300, :5])
 
 
+def test_noalloc_topk_random_request_sweep():
+    """Seeded sweep (RECO_FUZZ_MULT / RECO_FUZZ_SEED scale it, tools/fuzz_run.sh): random table sizes, user ranges and lists,
+    candidate lists with repeats, masks, every k, back to back on the one shared scratch array -- always the workspace form's bits."""
+    import os
+    mult = max(1, int(os.environ.get("RECO_FUZZ_MULT", "1"))); seed = int(os.environ.get("RECO_FUZZ_SEED", "0"))
+    rng = np.random.default_rng(4711 + seed)
+    for case in range(6 * mult):
+        n_users = int(rng.integers(1, 4000)); n_items = int(rng.choice([rng.integers(10, 400), rng.integers(400, 30000)]))
+        _, tower = _tower(n_users, n_items, 100 + case)
+        dev = tower.device
+        for call in range(3):                                  # several calls per model, sizes going up and down
+            k = int(rng.integers(1, min(n_items, 128) + 1))
+            cands = torch.from_numpy(rng.integers(0, n_items, int(rng.integers(k, n_items + 50)))).to(dev) if call == 1 else None
+            N = cands.numel() if cands is not None else n_items
+            if call == 2:
+                users = torch.from_numpy(rng.integers(0, n_users, int(rng.integers(1, 3000)))).to(dev); base = 0; U = users.numel()
+            else:
+                users = None; base = int(rng.integers(0, n_users)); U = int(rng.integers(1, n_users - base + 1))
+            ex = (torch.from_numpy(rng.random((U, N)) < 0.1)).to(torch.uint8).to(dev) if (case + call) % 2 and U * N < 30_000_000 else None
+            (ids_a, vals_a), (ids_b, vals_b) = _both(tower, users, base, U, cands, N, k, ex)
+            assert np.array_equal(ids_a, ids_b) and np.array_equal(vals_a.view(np.uint32), vals_b.view(np.uint32)), (case, call, n_users, n_items, U, N, k)
+
+
 def test_noalloc_topk_rejects_what_does_not_fit_and_launches_nothing():
     from recommender_amd import _lib
     L = _lib.lib()
