@@ -121,7 +121,10 @@ __global__ __launch_bounds__(256, SHORT ? (MASKED ? RECO_TOPK_SHORT_OCC_MASKED :
     P.clear();
     u64 thr = 0;
     // (Measured and dropped in round 2: a float pre-filter "score >= k-th score" in front of the key build, per 256-element block
-    // 0.354 -> 0.383 ms and per 64-element offer 0.354 -> 0.353 ms on 256 x 1M, k = 100: the key build is not what bounds the scan.)
+    // 0.354 -> 0.383 ms and per 64-element offer 0.354 -> 0.353 ms on 256 x 1M, k = 100: the key build is not what bounds the scan.
+    // Round 3, the fused sink's float pre-compare (no key, no exact compare unless some lane reaches the k-th score) in front of every
+    // offer, same-box A/B: 6,038 x 3,533 0.0308 -> 0.0326 ms, masked 6,040 x 3,706 0.0373 -> 0.0389, 2,048 x 65,536 0.2084 -> 0.2134,
+    // 256 x 1M 0.2530 -> 0.2356: three of four shapes lose -- the extra branch per element costs more than the keys it saves.)
     if constexpr (VEC == 4) {
         constexpr int UN = SHORT ? (MASKED ? RECO_TOPK_UN_SHORT_MASKED : RECO_TOPK_UN_SHORT) : (MASKED ? RECO_TOPK_UN_MASKED : RECO_TOPK_UN);
         // the masks travel with the scores: mk > 0 marks an excluded element.  (Read where they are applied -- after the scores

@@ -102,6 +102,13 @@ def main(which):
         measure("topk 115056x100 k=10", lambda: ops.topk_rows(s, 10))
         s2 = torch.randn(6038, 3552, device=dev)[:, :3533]
         measure("topk 6038x3533 k=10", lambda: ops.topk_rows(s2, 10))
+        R = ((torch.rand(6040, 3706, device=dev) < 0.045) * torch.randint(1, 6, (6040, 3706), device=dev)).float()
+        s3 = torch.randn(6040, 3712, device=dev)[:, :3706]
+        measure("topk 6040x3706 k=10 masked by the rating matrix", lambda: ops.topk_rows_seen(s3, 10, R))
+        s4 = torch.randn(256, 1_000_000, device=dev)
+        measure("topk 256x1M k=100", lambda: ops.topk_rows(s4, 100))
+        s5 = torch.randn(2048, 65536, device=dev)
+        measure("topk 2048x65536 k=100", lambda: ops.topk_rows(s5, 100))
 
 
 if __name__ == "__main__":
