@@ -120,6 +120,10 @@ __device__ __forceinline__ f32x4 load_k4(const float* row, int64_t k, int64_t K)
 // Same-box A/B (tools/gemm_variant_ab.sh): AutoRec decoder 0.243 -> 0.234 ms, split-K encoder 0.237 -> 0.232, 4096^3 1.12 -> 1.095;
 // single-buffered launches with fewer than 12 K tiles lose (a workgroup has nothing in flight while it waits: the Hybrid
 // encoders' K = 256 / 128 layers +1.5 %) and keep the register path.
+#ifndef RECO_GEMM_ONE_OCC
+#define RECO_GEMM_ONE_OCC 4        // workgroups per CU the single-buffered LDS-direct form is compiled for (same-box A/B, AutoRec decoder:
+                                   // 3: 0.2211-0.2214 ms   4: 0.2181-0.2224   5: 0.2173-0.2184 -- inside the run-to-run spread)
+#endif
 #ifdef RECO_DIAG_GEMM_TRACE         // diagnostic builds only: phase time stamps of every workgroup's thread 0 (tools/gemm_trace.py)
 static __device__ unsigned long long g_gemm_trace[8 * 8192];
 #define GEMM_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_trace[8 * blockIdx.x + (i)] = wall_clock64(); } while (0)
@@ -128,7 +132,7 @@ static __device__ unsigned long long g_gemm_trace[8 * 8192];
 #endif
 
 template <int BM, int BN, int VEC, bool AT, bool SPLIT, bool ONE, bool DMAT>
-__global__ __launch_bounds__(256, DMAT ? (ONE ? 4 : 2) : 1) void linear_kernel(LinArgs a)
+__global__ __launch_bounds__(256, DMAT ? (ONE ? RECO_GEMM_ONE_OCC : 2) : 1) void linear_kernel(LinArgs a)
 {
     GEMM_STAMP(0);
     static_assert(!DMAT || (!AT && !SPLIT && VEC == 4), "LDS-direct staging: plain exact form with 16-byte aligned rows only");
