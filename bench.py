@@ -297,7 +297,7 @@ def mfma_roofline(kernel, pairs_per_launch, kernel_ms, launches, traffic=None, t
     return r
 
 
-def parallelism_text(world, share_gpus, pipelined, reserve):
+def parallelism_text(world, share_gpus, pipelined, reserve, depth=2):
     """What the ranks actually do with the top-k lists, in words (config.parallelism)."""
     if world == 1:
         from recommender_amd.dist import force_collective_setting
@@ -310,12 +310,13 @@ def parallelism_text(world, share_gpus, pipelined, reserve):
         how = ("one blocking all-gather per step; the pipelined form failed and the ranks were restarted" if os.environ.get("RECO_BENCH_FELL_BACK") == "1"
                else "one blocking all-gather per step (RECO_BENCH_SYNC_GATHER=1)")
     elif reserve:
-        how = ("pipelined: the gather of step i is enqueued behind step i's top-k and awaited before step i + 2; the tile kernels leave "
-               "%d of the CUs free (RECO_RESERVE_CUS) so that the gather kernel can run under step i + 1's tile launch" % reserve)
+        how = ("pipelined: the gather of step i is enqueued behind step i's top-k and awaited before step i + %d; the tile kernels leave "
+               "%d of the CUs free (RECO_RESERVE_CUS) so that the gather kernel can run under step i + 1's tile launch" % (depth, reserve))
     else:
-        how = ("pipelined: the gather of step i is enqueued behind step i's top-k and awaited before step i + 2; the persistent tile "
-               "kernel fills every CU's LDS, so the gather kernel runs in the gap between two tile launches (beside the projection / "
-               "select kernels), not under one; RECO_RESERVE_CUS=r would keep r CUs free for it")
+        how = ("pipelined, %d buffers in flight: the gather of step i is enqueued behind step i's top-k and awaited before step i + %d; "
+               "the persistent tile kernel fills every CU's LDS, so the gather kernel may only find CUs in the gap between two tile "
+               "launches (beside the select kernels) -- with three buffers it has had a whole step by the time it is awaited; "
+               "RECO_RESERVE_CUS=r would keep r CUs free for it" % (depth, depth))
     return "user-sharded x%d, replicated tables, %s all-gather of packed top-k (%s)" % (world, backend, how)
 
 
@@ -379,6 +380,9 @@ def main_rank(args):
     pipelined = os.environ.get("RECO_BENCH_SYNC_GATHER", "0") != "1"
     from recommender_amd.dist import reserved_cus_setting
     reserve = reserved_cus_setting() if world > 1 else 0
+    # buffers in flight (dist.TopkGather): with peers a third buffer lets a gather that only found CUs when the NEXT tile launch ended
+    # complete before it is awaited; alone it changes nothing (profiles/r03_force_gather_n1.jsonl)
+    depth = int(os.environ.get("RECO_GATHER_DEPTH", "3" if world > 1 else "2"))
 
     spread = {}                                   # per-launch spread of the tile kernel's duration, by precision
 
@@ -386,7 +390,7 @@ def main_rank(args):
         """W warm-up steps, then K timed steps between fences; (seconds max over ranks, mean ms of the tile kernel, ids, vals)."""
         ops.set_tower_precision(precision)
         # step i's all-gather is enqueued behind step i's kernels and not waited for before step i + 2 (N > 1; one rank gathers nothing)
-        pipe = TopkGather(model, K, total_users) if pipelined else _SyncGather()
+        pipe = TopkGather(model, K, total_users, depth=depth) if pipelined else _SyncGather()
         fence()                                  # first barrier of the process group (communicator set-up) outside everything timed
         # The device clock needs ~30 ms of load to settle after idle (a tile launch runs 3.6 ms cold, 3.13 ms settled), and any
         # host-side pause -- a process group's first barrier -- sends it back: `--precondition` untimed steps (the SAME fixed
@@ -461,7 +465,7 @@ def main_rank(args):
                        "layer1_projections": "P[u] = W1u eu + b1 and Q[i] = W1i ei are weight-only quantities the handle computes once per weight "
                                              "version at creation (as forward(user, item) always read them); a step is the tile kernel + the select "
                                              "(until late in round 3 every step recomputed them for its user range: two 9-us GEMM launches)",
-                       "parallelism": parallelism_text(world, args.share_gpus, pipelined, reserve)},
+                       "parallelism": parallelism_text(world, args.share_gpus, pipelined, reserve, depth)},
             "roofline": mfma_roofline("tower_tile_kernel<32,true>", pairs_per_rank, tile_ms, n_timed, traffic, traffic_src,
                                       algorithmic_bytes=pairs_per_rank * 4),
         }
