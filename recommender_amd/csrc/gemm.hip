@@ -124,6 +124,12 @@ __device__ __forceinline__ f32x4 load_k4(const float* row, int64_t k, int64_t K)
 #define RECO_GEMM_ONE_OCC 4        // workgroups per CU the single-buffered LDS-direct form is compiled for (same-box A/B, AutoRec decoder:
                                    // 3: 0.2211-0.2214 ms   4: 0.2181-0.2224   5: 0.2173-0.2184 -- inside the run-to-run spread)
 #endif
+#ifndef RECO_GEMM_AT_OCC
+#define RECO_GEMM_AT_OCC 4         // the 64 x 64 transposed-A form is compiled for four workgroups per CU (82 VGPRs, no AGPR copy of the
+                                   // accumulators): Hybrid dense item encoder 0.1365 -> 0.1316 ms same-box.  The 64 x 128 form would spill
+                                   // 52 bytes per lane at that budget and gains nothing (AutoRec dense encoder 0.2354 -> 0.2353 ms); three K
+                                   // slices instead of four (696 workgroups, all resident at three per CU) lose: 0.2354 -> 0.2417 ms.
+#endif
 #ifdef RECO_DIAG_GEMM_TRACE         // diagnostic builds only: phase time stamps of every workgroup's thread 0 (tools/gemm_trace.py)
 static __device__ unsigned long long g_gemm_trace[8 * 8192];
 #define GEMM_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_trace[8 * blockIdx.x + (i)] = wall_clock64(); } while (0)
@@ -132,7 +138,7 @@ static __device__ unsigned long long g_gemm_trace[8 * 8192];
 #endif
 
 template <int BM, int BN, int VEC, bool AT, bool SPLIT, bool ONE, bool DMAT>
-__global__ __launch_bounds__(256, DMAT ? (ONE ? RECO_GEMM_ONE_OCC : 2) : 1) void linear_kernel(LinArgs a)
+__global__ __launch_bounds__(256, DMAT ? (ONE ? RECO_GEMM_ONE_OCC : 2) : ((AT && !SPLIT && BM * BN <= 4096) ? RECO_GEMM_AT_OCC : 1)) void linear_kernel(LinArgs a)
 {
     GEMM_STAMP(0);
     static_assert(!DMAT || (!AT && !SPLIT && VEC == 4), "LDS-direct staging: plain exact form with 16-byte aligned rows only");
