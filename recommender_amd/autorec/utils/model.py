@@ -181,7 +181,7 @@ class AutoRec(nn.Module):
         H = extra["H"]
         if item_ids is not None:
             idx = torch.as_tensor(item_ids, dtype=torch.int64, device=H.device)
-            H = ops.gather_rows(H, idx) if H.shape[1] % 4 == 0 else H.index_select(0, idx)
+            H = ops.gather_rows(H, idx)                       # any hidden width (the one-float-per-thread form when it is not a multiple of 4)
         u = int(user_id)
         act = (None, 0.0, 0.0) if clamp is None else ("clamp", float(clamp[0]), float(clamp[1]))
         return ops.linear(H, wd[u:u + 1], bd[u:u + 1], act=act[0], lo=act[1], hi=act[2]).reshape(-1)

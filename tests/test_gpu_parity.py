@@ -897,7 +897,7 @@ def test_autorec_and_hybrid_random_size_sweep():
         k = int(rng.integers(1, min(I, 20) + 1))
         torch.manual_seed(1000 + case)
         # ---- AutoRec (item-based: rows of X are item vectors over the users) ----
-        H = int(rng.choice([16, 64, 500, 37 * 4]))
+        H = int(rng.choice([16, 64, 500, 37 * 4, 37]))
         a = AutoRec(U, I, H, True).eval()
         sd = {n: v.detach().numpy().copy() for n, v in a.state_dict().items()}
         a = a.cuda()
@@ -912,6 +912,10 @@ def test_autorec_and_hybrid_random_size_sweep():
             ids, vals = a.recommend_topk(Rd, k)
             oid, oval = O.topk_rows(O.mask_seen(np.ascontiguousarray(pred), R > 0), k)
             assert np.array_equal(ids.cpu().numpy(), oid) and np.array_equal(vals.cpu().numpy(), oval), ("autorec", case, U, I, H, k, sparse)
+        # the serving path: one user's scores for a list of items from the cached hidden layer (any hidden width)
+        a.cache_hidden(Rd)
+        uid = int(rng.integers(0, U)); items = rng.integers(0, I, 9)
+        assert_close(a.predict_user(uid, items).cpu().numpy(), ref64[uid, items], atol=atol, what="predict_user H=%d" % H)
         # ---- Hybrid ----
         rating = bool(case % 3 == 0)
         m = HybridAutoRecNCF(U, I, 64, [128, 64], rating_output=rating).eval()
