@@ -542,7 +542,11 @@ def test_linear_random_shape_sweep(tower_precision):
         ref = np.maximum(xs @ w.astype(np.float64).T + b, 0)
         scale = np.abs(xs) @ np.abs(w).astype(np.float64).T + np.abs(b)
         err = np.abs(y.cpu().numpy() - ref)
-        assert (err <= 4e-7 * scale + 1e-6).all(), (case, M, N, K, err.max())
+        # the parity gate (1e-5 relative) plus a few ulps of the sum of the terms' magnitudes.  The relative part matters for
+        # outliers: the long run (seed 21, case 1289: M 61, N 201, K 432) has ONE output of 80.19 whose k-ordered fp32 chain --
+        # numpy's float32 loop gives the same bits as the kernel -- is 1.27e-4 from fp64 against 1.24e-4 of scale slack alone
+        # (tools/repro_linear_case.py)
+        assert (err <= 1e-5 * np.abs(ref) + 4e-7 * scale + 1e-6).all(), (case, M, N, K, err.max())
         if out is not None:
             assert y.data_ptr() == out.data_ptr()
 
