@@ -244,6 +244,8 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void tower_tile_kernel(Tile
         const int64_t n0 = (tile % tiles_n) * TI;
         const int64_t u0 = (tile / tiles_n) * TUB;
         const int g_n = a.N - n0 > 32 ? TI / 32 : 1;           // the ragged last tile: no MFMAs for a column group past the catalog
+        // (handing those half-cost tiles out LAST for all user blocks, so that the launch ends on finer work units, was measured
+        // same-box on cfg2 -- 252 half tiles behind 13,860 whole ones: 3.152 -> 3.168 ms, four alternating runs; rejected)
         tile_queue_fetch(a, tid, next + gridDim.x, &s_next[(it + 1) & 1]);     // the tile after next
         if (next < tiles) { tile_stage_load<G, THREADS>(a, (next % tiles_n) * TI, next / tiles_n == 0, tid, st); p_stage_load(next); }
         const float* s_p = s_pbuf + (it & 1) * TUB * H1;
