@@ -306,3 +306,28 @@ def test_autorec_cached_hidden_layer_is_dropped_when_weights_change(g3):
     after = m.predict_user(5, clamp=None)
     torch.testing.assert_close(after, m.reconstruct_all(train, clamp=None)[5], rtol=1e-5, atol=1e-5)
     assert not torch.equal(before, m.predict_user(5))
+
+
+def test_run_time_scheduled_paths_repeat_bit_for_bit(g2):
+    """The tile kernels pull tiles from a work queue, the fused score + top-k hands out item tiles and partial lists through
+    atomics, the CSR encoder adds per-segment partial sums, the Hybrid runs its encoders on two streams: WHO computes a tile
+    changes from run to run, the bits must not (tools/soak.py is the 3,000-repetition form of this test)."""
+    from recommender_amd.autorec.utils.model import AutoRec
+    from recommender_amd.helpers import NCF
+    from recommender_amd.hybridautorecncf.model import HybridAutoRecNCF
+    torch.manual_seed(9)
+    rng = np.random.default_rng(9)
+    m = NCF(1500, 5000, 32, 3, 0.0, "NeuMF-end").eval().cuda()
+    tower = m._tower(torch.device("cuda", 0))
+    R = torch.from_numpy(((rng.random((700, 900)) < 0.05) * rng.integers(1, 6, (700, 900))).astype(np.float32)).cuda()
+    a = AutoRec(700, 900, 500, True).eval().cuda()
+    a.attach_ratings(R)
+    h = HybridAutoRecNCF(700, 900, 64, [128, 64], rating_output=True).eval().cuda()
+    h.attach_ratings(R)
+    paths = {"two-kernel top-k": lambda: tower.score_topk(None, 10), "fused top-k": lambda: tower.score_topk(None, 100, fused=True),
+             "autorec csr": lambda: a.recommend_topk(R, 10), "hybrid csr, two streams": lambda: h.score_all(R, k=10, mask_seen=True)}
+    for name, fn in paths.items():
+        first = [t.clone() for t in fn()]
+        for rep in range(25):
+            got = fn()
+            assert torch.equal(got[0], first[0]) and torch.equal(got[1].view(torch.int32), first[1].view(torch.int32)), (name, rep)
