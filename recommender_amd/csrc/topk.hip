@@ -38,6 +38,10 @@
 // are 5.9 waves per SIMD, the kernel held 102 / 130 VGPRs (4 / 3 waves per SIMD: two rounds).  With ONE float4 in flight per
 // lane and the register budget of six waves per SIMD (no spill; two in flight spill under the mask) the whole grid is resident
 // at once: 0.0362 / 0.0455 -> 0.0292 / 0.0348 ms.
+// Later in round 3, the opposite trade, measured and rejected: a whole row put in flight at once with LDS-direct loads (one wave per
+// workgroup, 1 KB of LDS per 256 elements, offers out of LDS: one memory round trip per row instead of fourteen) -- correct, and
+// slower: 0.0294 -> 0.0429 / 0.0372 -> 0.0542 ms.  Ten such rows fit a CU where this kernel keeps twenty-four waves: the scan is
+// short of instruction issue slots, not of bytes in flight.
 #ifndef RECO_TOPK_UN_SHORT
 #define RECO_TOPK_UN_SHORT 1  // segments up to RECO_TOPK_SHORT_SEG elements
 #endif
